@@ -1,0 +1,106 @@
+"""Background-cosmology providers (the "cosmology seam").
+
+The reference builds a CAMB (or CLASS) object in ``Cosmology._init_cosmology``
+(hmvec/cosmology.py:161-211) and asks it for H(z), distances and Omega_nu.  Those
+are *inputs* to the halo-model hot path, not part of it, so here they sit behind
+a tiny provider interface:
+
+    hubble_parameter(z)  [km/s/Mpc]      h_of_z(z)  [1/Mpc]
+    comoving_radial_distance(z) [Mpc]    angular_diameter_distance(z) [Mpc]
+    angular_diameter_distance2(z1, z2)   get_Omega(name)       YHe
+
+``AnalyticBackground`` is a closed-form (no radiation, no massive neutrinos)
+w0-wa CDM background; it is what the golden fixtures were generated with (the
+generator registers it as the stand-in ``camb`` results object), so both sides
+of every parity test see bit-identical inputs.  ``CambBackground`` forwards to a
+real CAMB install when one is importable.
+"""
+import numpy as np
+
+C_KMS = 299792.458  # speed of light [km/s]; same constant as hmvec/cosmology.py:27
+
+# Fixed 96-node Gauss-Legendre rule for chi(z); deterministic, vectorised.
+_GL_X, _GL_W = np.polynomial.legendre.leggauss(96)
+
+
+class AnalyticBackground:
+    def __init__(self, H0, ombh2, omch2, omk=0.0, w0=-1.0, wa=0.0, YHe=None):
+        self.H0 = float(H0)
+        h = self.H0 / 100.0
+        self.omm = (ombh2 + omch2) / h ** 2
+        self.omk = float(omk)
+        self.omde = 1.0 - self.omm - self.omk
+        self.w0 = float(w0)
+        self.wa = float(wa)
+        self.YHe = 0.2454 if YHe is None else YHe
+
+    def _E(self, z):
+        z = np.asarray(z, dtype=np.float64)
+        a1 = 1.0 + z
+        de = a1 ** (3.0 * (1.0 + self.w0 + self.wa)) * np.exp(-3.0 * self.wa * z / a1)
+        return np.sqrt(self.omm * a1 ** 3 + self.omk * a1 ** 2 + self.omde * de)
+
+    def hubble_parameter(self, z):
+        return self.H0 * self._E(z)
+
+    def h_of_z(self, z):
+        return self.hubble_parameter(z) / C_KMS
+
+    def _chi_flat(self, z):
+        z = np.asarray(z, dtype=np.float64)
+        zz = np.atleast_1d(z)[..., None]
+        nodes = 0.5 * zz * (_GL_X + 1.0)
+        val = 0.5 * zz[..., 0] * np.sum(_GL_W / self._E(nodes), axis=-1)
+        return (C_KMS / self.H0) * val.reshape(z.shape)
+
+    def comoving_radial_distance(self, z):
+        return self._chi_flat(z)
+
+    def _transverse(self, chi):
+        if self.omk == 0.0:
+            return chi
+        rk = (C_KMS / self.H0) / np.sqrt(abs(self.omk))
+        return rk * (np.sinh(chi / rk) if self.omk > 0 else np.sin(chi / rk))
+
+    def angular_diameter_distance(self, z):
+        z = np.asarray(z, dtype=np.float64)
+        return self._transverse(self._chi_flat(z)) / (1.0 + z)
+
+    def angular_diameter_distance2(self, z1, z2):
+        z1 = np.asarray(z1, dtype=np.float64)
+        z2 = np.asarray(z2, dtype=np.float64)
+        return self._transverse(self._chi_flat(z2) - self._chi_flat(z1)) / (1.0 + z2)
+
+    def get_Omega(self, name):
+        if name == "nu":
+            return 0.0
+        if name in ("baryon", "cdm", "de", "K"):
+            raise NotImplementedError(name)
+        raise ValueError(name)
+
+
+class CambBackground:
+    """Thin forwarder to a real CAMB results object (only if camb is installed).
+
+    Mirrors the ``camb.set_params`` call at hmvec/cosmology.py:161-176.
+    """
+
+    def __init__(self, params, halofit=None):
+        import camb  # noqa: F401  (ImportError propagates: caller decides)
+
+        YHe = params.get("YHe")
+        self.pars = camb.set_params(
+            ns=params["ns"], As=params["As"], r=params.get("r", 0.0), H0=params["H0"],
+            ombh2=params["ombh2"], omch2=params["omch2"], mnu=params["mnu"],
+            omk=params["omk"], tau=params["tau"], nnu=params["nnu"],
+            num_massive_neutrinos=params["num_massive_neutrinos"],
+            w=params["w0"], wa=params["wa"], dark_energy_model="ppf",
+            halofit_version=params["default_halofit"] if halofit is None else halofit,
+            AccuracyBoost=2, pivot_scalar=params["pivot_scalar"], YHe=YHe)
+        self.pars.WantTransfer = True
+        self.pars.WantTensors = True
+        self.results = camb.get_background(self.pars)
+        self.YHe = self.pars.YHe
+
+    def __getattr__(self, name):
+        return getattr(self.results, name)

@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the UNMODIFIED reference (simonsobs/hmvec,
+mounted read-only at /root/reference) in this container.
+
+Only runs where /root/reference exists (never on the GPU box).  Output: small
+``tests/golden/*.npz`` files holding inputs + every intermediate + outputs of the
+hot path.  Fixtures are data; no reference source is written anywhere.
+
+How the reference is made importable: it does ``import camb`` at
+module scope (hmvec/hmvec.py:5, hmvec/cosmology.py:5) and camb is not installed
+(no network).  camb only supplies *inputs* to the path (H(z), distances,
+Omega_nu), so a stand-in module is registered in ``sys.modules`` whose
+``get_background`` returns this repo's ``AnalyticBackground``; with
+``accuracy='low'`` P(k) comes from the reference's own Eisenstein-Hu code.  The
+path under test (hmvec/hmvec.py, fft.py, tinker.py, utils.py and
+Cosmology.get_sigma2_R) runs exactly as shipped.
+
+Two environment shims, both recorded in DESIGN.md:
+  * tinker.py:64 reads ``<pkg>/../data/alpha_consistency.txt`` which does not
+    exist in the checkout (the file is at ``<pkg>/data/``): np.loadtxt is
+    redirected for that one path.
+  * Limber (cosmology.py:890-899) uses scipy.interpolate.interp2d and
+    si.dfitpack.bispeu, both removed in scipy 1.15: a bilinear shim is injected
+    for the Limber fixtures only.
+
+Usage:  python tools/make_golden.py [--out tests/golden]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+from hmvec_amd.background import AnalyticBackground  # noqa: E402
+
+
+def install_standin_camb():
+    camb = types.ModuleType("camb")
+    model = types.ModuleType("camb.model")
+    model.NonLinear_none, model.NonLinear_both = 0, 3
+
+    class Pars:
+        pass
+
+    def set_params(**kw):
+        p = Pars()
+        p.kw = dict(kw)
+        p.YHe = kw.get("YHe")
+        if p.YHe is None:
+            p.YHe = 0.2454
+        return p
+
+    def get_background(p):
+        k = p.kw
+        return AnalyticBackground(H0=k["H0"], ombh2=k["ombh2"], omch2=k["omch2"],
+                                  omk=k.get("omk", 0.0), w0=k.get("w", -1.0),
+                                  wa=k.get("wa", 0.0), YHe=p.YHe)
+
+    camb.set_params = set_params
+    camb.get_background = get_background
+    camb.model = model
+    sys.modules["camb"] = camb
+    sys.modules["camb.model"] = model
+
+
+def install_loadtxt_redirect():
+    real = np.loadtxt
+    bad = os.path.normpath(os.path.join(REF, "data", "alpha_consistency.txt"))
+    good = os.path.join(REF, "hmvec", "data", "alpha_consistency.txt")
+
+    def loadtxt(fname, *a, **k):
+        if isinstance(fname, str) and os.path.normpath(fname) == bad:
+            fname = good
+        return real(fname, *a, **k)
+
+    np.loadtxt = loadtxt
+
+
+def install_limber_shims():
+    """interp2d / dfitpack.bispeu were removed from scipy>=1.14; the reference's
+    Limber code needs both.  Bilinear spline with the same (kx=ky=1) semantics."""
+    import scipy.interpolate as si
+    from scipy.interpolate import RectBivariateSpline
+
+    class interp2d:  # noqa: N801
+        def __init__(self, x, y, z, bounds_error=False):
+            self._s = RectBivariateSpline(np.asarray(x), np.asarray(y), np.asarray(z).T,
+                                          kx=1, ky=1, s=0)
+            tx, ty, c = self._s.tck
+            self.tck = (tx, ty, c, 1, 1)
+
+    class _Dfit:
+        @staticmethod
+        def bispeu(tx, ty, c, kx, ky, x, y):
+            from scipy.interpolate import _dfitpack
+            return _dfitpack.bispeu(tx, ty, c, kx, ky, x, y)
+
+    si.interp2d = interp2d
+    si.dfitpack = _Dfit
+    import hmvec.cosmology as rc
+    rc.interp2d = interp2d
+
+
+def cosmo_inputs(h, zs):
+    """Everything the path consumes from the cosmology layer, as arrays."""
+    d = dict(
+        h=h.h, omm0=h.omm0, YHe=h.YHe,
+        Pzk=h.Pzk, hubble_zs=h.hubble_parameter(h.zs), hubble_0=h.hubble_parameter(0.0),
+        h_of_z_zs=h.h_of_z(h.zs), rho_crit_zs=h.rho_critical_z(h.zs),
+        rho_crit_0=h.rho_critical_z(0.0), rho_matter_0=h.rho_matter_z(0),
+        chi_zs=h.comoving_radial_distance(h.zs),
+    )
+    if hasattr(h, "sPzk"):
+        d["sPzk"] = h.sPzk
+    return d
+
+
+def run_case(hm, tag, zs, ks, ms, *, params=None, mass_function="sheth-torman", mdef="vir",
+             family="AGN", nxs=512, xmax=20.0, corr="max", ngal_mode=False,
+             central=False, pres=True, numeric_nfw=None, batt_override=None, limber=None):
+    params = dict(params or {})
+    out = dict(zs=zs, ks=ks, ms=ms)
+    meta = dict(params=params, mass_function=mass_function, mdef=mdef, family=family,
+                nxs=nxs, xmax=xmax, corr=corr, ngal_mode=ngal_mode, central=central,
+                pres=pres, numeric_nfw=numeric_nfw, batt_override=batt_override,
+                limber=limber)
+    h = hm.HaloModel(zs, ks, ms=ms, params=dict(params), mass_function=mass_function,
+                     mdef=mdef, accuracy="low")
+    for k, v in cosmo_inputs(h, zs).items():
+        out["in_" + k] = np.asarray(v)
+    out["sigma2"], out["nzm"], out["bh"] = h.sigma2, h.nzm, h.bh
+    out["cs"] = h.concentration()
+    out["rvir"] = h.rvir(ms[None, :], zs[:, None])
+    out["uk_nfw"] = h.uk_profiles["nfw"]
+
+    # mass conversion intermediates (hmvec.py:216-225)
+    rhoc = h.rho_critical_z(zs)
+    d1 = rhoc * h.deltav(zs) if mdef == "vir" else h.rho_matter_z(zs) * 200.0
+    out["m200c"] = hm.mdelta_from_mdelta(ms, out["cs"], d1, 200.0 * rhoc)
+
+    h.add_battaglia_profile("electron", family=family, xmax=xmax, nxs=nxs,
+                            param_override=batt_override)
+    out["uk_electron"] = h.uk_profiles["electron"]
+
+    if numeric_nfw is not None:
+        nn, xm = numeric_nfw
+        _, u = h.add_nfw_profile("nfwnum", numeric=True, nxs=nn, xmax=xm)
+        out["uk_nfwnum"] = u
+
+    if ngal_mode:
+        h.add_hod("g0", mthresh=10 ** 10.5 + zs * 0.0)
+        target = h.hods["g0"]["ngal"] * 1.37
+        h.add_hod("g", ngal=target, corr=corr,
+                  central_profile_name="electron" if central else None)
+        out["ngal_target"] = target
+    else:
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, corr=corr,
+                  central_profile_name="electron" if central else None)
+    for key in ("Nc", "Ns", "NsNsm1", "NcNs", "ngal", "bg", "log10mthresh"):
+        out["hod_" + key] = np.asarray(h.hods["g"][key])
+
+    names = ["nfw", "electron", "g"]
+    if pres:
+        h.add_battaglia_pres_profile("y", nxs=nxs, xmax=xmax)
+        out["pk_y"] = h.pk_profiles["y"]
+        names.append("y")
+    for i, a in enumerate(names):
+        for b in names[i:]:
+            out[f"P1h_{a}_{b}"] = h.get_power_1halo(a, b)
+            out[f"P2h_{a}_{b}"] = h.get_power_2halo(a, b)
+    # argument-order quirk (hmvec.py:510-511): (g, g) only; cross order symmetric
+    out["P1h_electron_nfw"] = h.get_power_1halo("electron", "nfw")
+    b1 = 1.0 + 0.1 * np.arange(zs.size)
+    b2 = 2.0 - 0.05 * np.arange(zs.size)
+    out["b1_in"], out["b2_in"] = b1, b2
+    out["P2h_g_nfw_bin"] = h.get_power_2halo("g", "nfw", b1_in=b1, b2_in=b2)
+    out["P_tot_g_electron"] = h.get_power("g", "electron")
+
+    if limber is not None:
+        ells = np.asarray(limber["ells"], dtype=float)
+        Pmm = out["P1h_nfw_nfw"] + out["P2h_nfw_nfw"]
+        Pgm = out["P1h_nfw_g"] + out["P2h_nfw_g"]
+        Pgg = out["P1h_g_g"] + out["P2h_g_g"]
+        out["ells"] = ells
+        out["C_kk"] = h.C_kk(ells, zs, ks, Pmm, lzs1=limber["lzs"], lzs2=limber["lzs"])
+        out["C_kg"] = h.C_kg(ells, zs, ks, Pgm, gzs=limber["gzs"], lzs=limber["lzs"])
+        gz = np.linspace(0.3, 1.2, 7)
+        gd = np.exp(-0.5 * ((gz - 0.7) / 0.2) ** 2)
+        out["gz_dndz"] = np.stack([gz, gd])
+        out["C_kg_dndz"] = h.C_kg(ells, zs, ks, Pgm, gzs=gz, gdndz=gd, lzs=limber["lzs"])
+        out["C_gg_dndz"] = h.C_gg(ells, zs, ks, Pgg, gzs=gz, gdndz=gd)
+        out["lensing_window"] = h.lensing_window(zs, limber["lzs"])
+    out["meta_json"] = np.array(json.dumps(meta, default=lambda o: np.asarray(o).tolist()))
+    return out
+
+
+def run_readme_anchor(hm):
+    """Config 1/2 (README grid) at full size; only a strided sub-sample is stored."""
+    zs = np.linspace(0.0, 3.0, 20)
+    ms = np.geomspace(2e10, 1e17, 200)
+    ks = np.geomspace(1e-4, 100, 1001)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low")
+    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=5000)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    zi, mi, ki = slice(None, None, 3), slice(None, None, 13), slice(None, None, 20)
+    out = dict(zs=zs, ms=ms, ks=ks, zstride=3, mstride=13, kstride=20)
+    out["sigma2"] = h.sigma2[zi, mi]
+    out["nzm"] = h.nzm[zi, mi]
+    out["bh"] = h.bh[zi, mi]
+    out["uk_nfw"] = h.uk_profiles["nfw"][zi, mi, ki]
+    out["uk_electron"] = h.uk_profiles["electron"][zi, mi, ki]
+    for k in ("ngal", "bg"):
+        out["hod_" + k] = h.hods["g"][k]
+    names = ["nfw", "electron", "g"]
+    for i, a in enumerate(names):
+        for b in names[i:]:
+            out[f"P1h_{a}_{b}"] = h.get_power_1halo(a, b)[:, ki]
+            out[f"P2h_{a}_{b}"] = h.get_power_2halo(a, b)[:, ki]
+    out["meta_json"] = np.array(json.dumps(dict(config="README C1/C2", nxs=5000, xmax=20)))
+    return out
+
+
+def run_unit_pins(hm):
+    """Known-answer pins the reference itself carries."""
+    import hmvec.fft as rfft
+    import hmvec.utils as rutils
+    import hmvec.tinker as rtinker
+    out = {}
+    # fft_integral on the authors' test input (bin/tests.py:8-11): dx=1e-3, x<20
+    x = np.arange(1e-3, 20.0, 1e-3)
+    kt, ukt = rfft.fft_integral(x, np.exp(-x ** 2 / 2.0))
+    out["fftint_x"] = x
+    out["fftint_k"], out["fftint_u"] = kt[:400], ukt[:400]
+    # bisection self-test (hmvec/utils.py:45-51)
+    xs = np.array([2.0, 4.0, 6.0])
+    out["bisect_x"] = xs
+    out["bisect_y"] = rutils.vectorized_bisection_search(xs, lambda y: np.sqrt(y), (1, 40),
+                                                         "increasing", rtol=1e-4, verbose=False)
+    nu = np.geomspace(0.2, 6.0, 40)[None, :] + np.zeros((5, 1))
+    z = np.array([0.0, 0.7, 2.2, 3.0, 4.5])[:, None]
+    out["tinker_nu"], out["tinker_z"] = nu, z
+    out["tinker_bias"] = rtinker.bias(nu)
+    out["tinker_fnu"] = rtinker.f_nu(nu, z)
+    izs, ial = np.loadtxt(os.path.join(REF, "data", "alpha_consistency.txt"), unpack=True)
+    out["tinker_alpha_z"], out["tinker_alpha"] = izs, ial
+    # HOD helper functions on a grid
+    zz = np.array([0.0, 0.8, 0.80001, 2.0])[:, None]
+    lm = np.linspace(8.0, 13.0, 30)[None, :]
+    out["shmr_z"], out["shmr_logmstar"] = zz, lm
+    out["shmr_Mhalo_stellar"] = hm.Mhalo_stellar(zz, lm)
+    lmh = np.linspace(10.0, 16.0, 25)[None, :]
+    out["shmr_logmhalo"] = lmh
+    out["shmr_Mstellar_halo"] = hm.Mstellar_halo(zz, lmh)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--skip-readme", action="store_true")
+    args = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("reference checkout not present; goldens can only be generated in the build container")
+    warnings.filterwarnings("ignore")
+    install_standin_camb()
+    install_loadtxt_redirect()
+    sys.path.insert(0, REF)
+    import hmvec as hm  # the unmodified reference
+    install_limber_shims()
+    os.makedirs(args.out, exist_ok=True)
+
+    def save(name, d):
+        path = os.path.join(args.out, name + ".npz")
+        np.savez_compressed(path, **d)
+        print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
+
+    save("unit_pins", run_unit_pins(hm))
+
+    ks = np.geomspace(1e-4, 100, 40)
+    ms = np.geomspace(2e10, 1e17, 32)
+    # A: defaults (ST, vir, AGN, corr=max, mthresh); z grid has z=0, both SHMR branches, z=3.0
+    save("case_a", run_case(hm, "a", np.array([0.0, 0.5, 1.2, 3.0]), ks, ms, nxs=1000,
+                            numeric_nfw=(4000, 50.0),
+                            limber=None))
+    # B: tinker + mean + SH + corr=min + ngal bisection + miscentred central + odd sigma2_numks
+    save("case_b", run_case(hm, "b", np.array([0.1, 0.8, 1.7, 3.0, 3.4]),
+                            np.geomspace(2e-4, 50, 33), np.geomspace(1e11, 5e15, 24),
+                            params=dict(sigma2_numks=2001, omch2=0.125, H0=70.0, ns=0.97),
+                            mass_function="tinker", mdef="mean", family="SH", nxs=600,
+                            xmax=15.0, corr="min", ngal_mode=True, central=True,
+                            batt_override=dict(battaglia_gas_gamma=-0.25, rho0_A0=4100.0)))
+    # C: Limber fixtures (no z=0: chi=0 makes the reference NaN), ST/vir
+    save("case_c", run_case(hm, "c", np.linspace(0.05, 3.0, 9), np.geomspace(1e-4, 100, 48),
+                            np.geomspace(2e10, 1e17, 28), nxs=400, pres=False,
+                            params=dict(sigma2_numks=4000),
+                            limber=dict(ells=np.linspace(100, 6000, 12), lzs=2.5, gzs=0.8)))
+    if not args.skip_readme:
+        save("readme_c1", run_readme_anchor(hm))
+
+
+if __name__ == "__main__":
+    main()
