@@ -1,0 +1,210 @@
+"""ctypes binding of libhmgrid.so (C ABI in include/hmgrid.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this
+module raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C hmvec_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmgrid.so")
+ABI_VERSION = 1
+COMM_ID_BYTES = 128
+
+c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class MassFnParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("deltac", C.c_double), ("st_A", C.c_double),
+                ("st_a", C.c_double), ("st_p", C.c_double), ("rho_m0", C.c_double),
+                ("lnm_uniform", C.c_int), ("lnm_step", C.c_double)]
+
+
+class HodParams(C.Structure):
+    _fields_ = [("sig_log_mstellar", C.c_double), ("alphasat", C.c_double), ("Bsat", C.c_double),
+                ("betasat", C.c_double), ("Bcut", C.c_double), ("betacut", C.c_double),
+                ("corr", C.c_int)]
+
+
+class Tracer(C.Structure):
+    _fields_ = [("kind", C.c_int), ("d_prof", C.c_void_p), ("d_cprof", C.c_void_p),
+                ("d_Nc", C.c_void_p), ("d_Ns", C.c_void_p), ("d_NcNs", C.c_void_p),
+                ("d_NsNsm1", C.c_void_p), ("d_ngal", C.c_void_p),
+                ("d_bias_override", C.c_void_p)]
+
+
+MF_SHETH_TORMEN, MF_TINKER10 = 0, 1
+PROF_BATTAGLIA_GAS, PROF_BATTAGLIA_PRES = 1, 2
+TRACER_MATTER, TRACER_HOD, TRACER_PRESSURE = 0, 1, 2
+
+_I, _D, _P, _Z = C.c_int, C.c_double, C.c_void_p, C.c_size_t
+# name -> argtypes (restype is int for all but hmg_last_error); mirrors include/hmgrid.h
+SIGNATURES = {
+    "hmg_abi_version": [],
+    "hmg_ctx_create": [_I, C.POINTER(_P)],
+    "hmg_ctx_destroy": [_P],
+    "hmg_malloc": [_P, _Z, C.POINTER(_P)],
+    "hmg_free": [_P, _P],
+    "hmg_memcpy_h2d": [_P, _P, _P, _Z],
+    "hmg_memcpy_d2h": [_P, _P, _P, _Z],
+    "hmg_memcpy_d2d": [_P, _P, _P, _Z],
+    "hmg_sync": [_P],
+    "hmg_event_record": [_P, _I],
+    "hmg_elapsed_ms": [_P, _I, _I, C.POINTER(_D)],
+    "hmg_sigma2": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P],
+    "hmg_massfn": [_P, _I, _I, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P],
+    "hmg_halo_structure": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P],
+    "hmg_mdelta_convert": [_P, _I, _I, _P, _P, _P, _D, _P, _P, _P],
+    "hmg_nfw_analytic": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hmg_profile_rowparams": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, C.POINTER(_D * 9), _D, _D, _D,
+                              _D, _P, _P, _P, _P, _P, _P, _P],
+    "hmg_profile_fft": [_P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D, _D,
+                        _P, _P, _P, _P, _I, _P, _P],
+    "hmg_hod": [_P, _I, _I, C.POINTER(HodParams), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "hmg_power": [_P, _I, _I, _I, C.POINTER(Tracer), C.POINTER(Tracer), _P, _P, _P, _P, _P, _P,
+                  _D, _D, _P, _P],
+    "hmg_comm_unique_id": [C.c_char * COMM_ID_BYTES],
+    "hmg_comm_init": [_P, C.c_char * COMM_ID_BYTES, _I, _I],
+    "hmg_comm_allgather": [_P, _P, _P, _Z],
+    "hmg_comm_allgather_multi": [_P, _I, C.POINTER(_P), C.POINTER(_P), _Z],
+    "hmg_comm_barrier": [_P],
+    "hmg_comm_destroy": [_P],
+}
+
+_lib = None
+
+
+def load():
+    """Load libhmgrid.so once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU "
+            "fallback. Run `make -C hmvec_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.hmg_last_error.argtypes = []
+    lib.hmg_last_error.restype = C.c_char_p
+    if lib.hmg_abi_version() != ABI_VERSION:
+        raise ImportError(f"libhmgrid ABI {lib.hmg_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(load().hmg_last_error().decode("utf-8", "replace"))
+
+
+class DeviceArray:
+    """A C-contiguous fp64 array living in HBM, owned by a Context."""
+
+    __slots__ = ("ctx", "ptr", "shape", "_owner", "__weakref__")
+
+    def __init__(self, ctx, ptr, shape, owner=True):
+        self.ctx, self.ptr, self.shape, self._owner = ctx, ptr, tuple(int(s) for s in shape), owner
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def nbytes(self):
+        return self.size * 8
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        check(self.ctx.lib.hmg_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def view(self, offset_elems, shape):
+        """Non-owning window into this buffer (e.g. a z-slab)."""
+        v = DeviceArray(self.ctx, self.ptr + 8 * int(offset_elems), shape, owner=False)
+        v._owner = self  # keep parent alive
+        return v
+
+    def free(self):
+        if self._owner is True and self.ptr and self.ctx is not None and self.ctx.handle:
+            self.ctx.lib.hmg_free(self.ctx.handle, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per GPU / process: stream, scratch, rocFFT plans, RCCL communicator."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.hmg_ctx_create(int(device), C.byref(h)))
+        self.handle = h.value
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hmg_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # memory
+    def empty(self, shape):
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        n = int(np.prod(shape)) if len(shape) else 1
+        p = C.c_void_p()
+        check(self.lib.hmg_malloc(self.handle, n * 8, C.byref(p)))
+        return DeviceArray(self, p.value, shape)
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        d = self.empty(a.shape)
+        check(self.lib.hmg_memcpy_h2d(self.handle, d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
+    def copy(self, src):
+        d = self.empty(src.shape)
+        check(self.lib.hmg_memcpy_d2d(self.handle, d.ptr, src.ptr, src.nbytes))
+        return d
+
+    def sync(self):
+        check(self.lib.hmg_sync(self.handle))
+
+    def record(self, slot):
+        check(self.lib.hmg_event_record(self.handle, slot))
+
+    def elapsed_ms(self, s0, s1):
+        ms = C.c_double()
+        check(self.lib.hmg_elapsed_ms(self.handle, s0, s1, C.byref(ms)))
+        return ms.value
+
+    def call(self, name, *args):
+        check(getattr(self.lib, name)(self.handle, *args))
+
+
+def ptr(x):
+    """Device pointer of a DeviceArray or NULL."""
+    return None if x is None else x.ptr

@@ -1,0 +1,259 @@
+"""Host-side cosmology layer: the *inputs* to the halo-model hot path.
+
+Mirrors the slice of ``hmvec.cosmology.Cosmology`` the path consumes (SURVEY §8a
+rows A1/A2 and §8b "Cosmology seam"): parameter merging, background quantities via a
+provider (``hmvec_amd.background``), the Eisenstein-Hu ``accuracy='low'`` linear
+power spectrum, densities, and sigma^2(R,z) — the last one evaluated on the GPU.
+
+Reference lines are cited per method; nothing here is timed as part of the path
+except ``get_sigma2_R``.
+"""
+import warnings
+
+import numpy as np
+from scipy.special import hyp2f1
+
+from . import _native as nat
+from .background import AnalyticBackground, CambBackground, C_KMS
+from .params import default_params
+from .quadrature import simpson_weights
+
+cspeed = C_KMS
+
+
+def a2z(a):
+    return (1.0 / np.atleast_1d(a)) - 1.0
+
+
+class Cosmology(object):
+    """``Cosmology(params, halofit, engine, accuracy)`` as in hmvec/cosmology.py:51-65.
+
+    Extra keyword ``background`` injects a provider object; ``engine='analytic'`` selects
+    the closed-form background explicitly.  With ``engine='camb'`` (the reference default)
+    a real CAMB is used when importable; otherwise ``accuracy='low'`` falls back to the
+    analytic background and anything else raises ``ImportError``.
+    """
+
+    def __init__(self, params={}, halofit=None, engine="camb", accuracy="medium", background=None):
+        engine = engine.lower()
+        if engine not in ("camb", "class", "analytic"):
+            raise ValueError
+        if engine == "class":
+            raise NotImplementedError("CLASS engine is outside the MI355X hot-path scope")
+        self.accuracy = accuracy
+        self.engine = engine
+        if self.accuracy == "low" and (("S8" in params.keys()) or ("sigma8" in params.keys())):
+            raise ValueError("Can't use S8 or sigma8 with low accuracy.")
+        self.p = dict(params) if params is not None else {}
+        for key, val in default_params.items():
+            self.p.setdefault(key, val)
+        self._background = background
+        self._init_cosmology(self.p, halofit)
+
+    # ------------------------------------------------------------------ set-up
+    def _init_cosmology(self, params, halofit):
+        """hmvec/cosmology.py:138-225 (H0 parameterisation only)."""
+        if "theta100" in params:
+            raise NotImplementedError("theta100 parameterisation needs CAMB's solver")
+        if "omm" in params:
+            hh = params["H0"] / 100.0
+            params["omch2"] = params["omm"] * hh ** 2 - params["ombh2"]
+            print("WARNING: omm specified. Ignoring omch2.")
+        if self._background is None:
+            self._background = self._make_background(params, halofit)
+        self.params = params
+        self.h = params["H0"] / 100.0
+        self.omm0 = (params["omch2"] + params["ombh2"]) / self.h ** 2.0
+        self.omk0 = params["omk"]
+        self.oml0 = 1 - self.omm0 - self.omk0
+        self.as8 = params.get("as8", 1)
+        self.ombh2 = params["ombh2"]
+        self.YHe = self._background.YHe
+
+    def _make_background(self, params, halofit):
+        if self.engine == "analytic":
+            return self._analytic(params)
+        try:
+            return CambBackground(params, halofit)
+        except ImportError:
+            if self.accuracy != "low":
+                raise ImportError(
+                    "camb is not installed: accuracy='medium'/'high' need CAMB's P(k). "
+                    "Use accuracy='low' (Eisenstein-Hu) or pass background=/engine='analytic'.")
+            warnings.warn("camb not importable; using the analytic wCDM background")
+            return self._analytic(params)
+
+    @staticmethod
+    def _analytic(p):
+        return AnalyticBackground(p["H0"], p["ombh2"], p["omch2"], p["omk"], p["w0"], p["wa"],
+                                  p.get("YHe"))
+
+    # ------------------------------------------------------------------ background
+    def hubble_parameter(self, z):
+        """H(z) [km/s/Mpc]  (hmvec/cosmology.py:116-122)."""
+        return self._background.hubble_parameter(z)
+
+    def h_of_z(self, z):
+        """H(z) [1/Mpc]  (hmvec/cosmology.py:124-130)."""
+        return self._background.h_of_z(z)
+
+    def comoving_radial_distance(self, z):
+        return self._background.comoving_radial_distance(z)
+
+    def angular_diameter_distance(self, z1, z2=None):
+        if z2 is not None:
+            return self._background.angular_diameter_distance2(z1, z2)
+        return self._background.angular_diameter_distance(z1)
+
+    def get_Omega_nu(self):
+        return self._background.get_Omega("nu")
+
+    def rho_critical_z(self, z):
+        """hmvec/cosmology.py:239-243 (constants as in the reference)."""
+        Hz = self.hubble_parameter(z) * 3.241e-20
+        G = 6.67259e-11
+        rho = 3.0 * (Hz ** 2.0) / 8.0 / np.pi / G
+        return rho * 1.477543e37
+
+    def rho_matter_z(self, z):
+        """hmvec/cosmology.py:232-234."""
+        return self.rho_critical_z(0.0) * self.omm0 * (1 + np.atleast_1d(z)) ** 3.0
+
+    def omz(self, z):
+        return self.rho_matter_z(z) / self.rho_critical_z(z)
+
+    # ------------------------------------------------------------------ linear power, accuracy='low'
+    def D_growth_approx(self, a):
+        """Heath-77 growing mode for LCDM via 2F1 (hmvec/cosmology.py:297-314)."""
+        a = np.asarray(a)
+        x = (self.oml0 / self.omm0) ** (1.0 / 3.0) * a
+        return np.sqrt(1.0 + x ** 3.0) * hyp2f1(5 / 6.0, 3 / 2.0, 11 / 6.0, -x ** 3.0) * a
+
+    def D_growth(self, a, type="anorm", exact=False):
+        """hmvec/cosmology.py:317-332 (approximate branch only)."""
+        if exact:
+            raise NotImplementedError("exact growth needs CAMB/CLASS transfer outputs")
+        val = self.D_growth_approx(a) / self.D_growth_approx(1)
+        if type == "z0norm":
+            return val
+        if type == "anorm":
+            return val * self.D_growth_approx(1)
+        raise ValueError
+
+    def Tk(self, ks, type="eisenhu_osc"):
+        """Eisenstein & Hu 1998 transfer function (hmvec/cosmology.py:404-504).
+        Equation numbers refer to EH98; k in 1/Mpc on input, h/Mpc internally."""
+        h = self.h
+        k = np.asarray(ks, dtype=np.float64) / h
+        self.tcmb = 2.726
+        th2 = (self.tcmb / 2.7) ** 2
+        wm = self.params["omch2"] + self.params["ombh2"]
+        wb = self.params["ombh2"]
+        fb, fc = wb / wm, self.params["omch2"] / wm
+        k_eq = 7.46e-2 * wm / th2 / h                       # (3)
+        z_eq = 2.50e4 * wm / th2 ** 2                       # (2)
+        b1 = 0.313 * wm ** -0.419 * (1.0 + 0.607 * wm ** 0.674)
+        b2 = 0.238 * wm ** 0.223
+        z_d = 1291.0 * wm ** 0.251 / (1.0 + 0.659 * wm ** 0.828) * (1.0 + b1 * wb ** b2)   # (4)
+        R_d = 31.5 * wb / th2 ** 2 * (1.0e3 / z_d)          # (5)
+        R_eq = 31.5 * wb / th2 ** 2 * (1.0e3 / z_eq)
+        s = (2.0 / (3.0 * k_eq) * np.sqrt(6.0 / R_eq)
+             * np.log((np.sqrt(1.0 + R_d) + np.sqrt(R_eq + R_d)) / (1.0 + np.sqrt(R_eq))))   # (6)
+        k_silk = 1.6 * wb ** 0.52 * wm ** 0.73 * (1.0 + (10.4 * wm) ** -0.95) / h           # (7)
+        self._k_eq, self._z_eq, self._z_d, self._R_d, self._R_eq = k_eq, z_eq, z_d, R_d, R_eq
+        self.sh_d, self._k_silk = s, k_silk
+        if type == "eisenhu":
+            ag = 1.0 - 0.328 * np.log(431.0 * wm) * wb / wm + 0.38 * np.log(22.3 * wm) * fb ** 2
+            geff = self.omm0 * h * (ag + (1.0 - ag) / (1.0 + (0.43 * k * s) ** 4))
+            q = k * th2 / geff
+            L = np.log(2.0 * np.exp(1.0) + 1.8 * q)
+            Cq = 14.2 + 731.0 / (1.0 + 62.5 * q)
+            return L / (L + Cq * q * q)
+        if type != "eisenhu_osc":
+            return np.zeros_like(k)
+        # CDM piece (11,12,17-20)
+        a1 = (46.9 * wm) ** 0.670 * (1.0 + (32.1 * wm) ** -0.532)
+        a2 = (12.0 * wm) ** 0.424 * (1.0 + (45.0 * wm) ** -0.582)
+        alpha_c = a1 ** -fb * a2 ** (-fb ** 3)
+        bb1 = 0.944 / (1.0 + (458.0 * wm) ** -0.708)
+        bb2 = (0.395 * wm) ** -0.0266
+        beta_c = 1.0 / (1.0 + bb1 * (fc ** bb2 - 1.0))
+
+        def T0(kk, alpha, beta):                            # (10),(19)
+            q = kk / (13.41 * k_eq)
+            L = np.log(np.exp(1.0) + 1.8 * beta * q)
+            Cq = 14.2 / alpha + 386.0 / (1.0 + 69.9 * q ** 1.08)
+            return L / (L + Cq * q * q)
+
+        f = 1.0 / (1.0 + (k * s / 5.4) ** 4)
+        Tc = f * T0(k, 1.0, beta_c) + (1.0 - f) * T0(k, alpha_c, beta_c)
+        # baryon piece (14,15,21-24)
+        y = (1.0 + z_eq) / (1.0 + z_d)
+        sq = np.sqrt(1.0 + y)
+        G = y * (-6.0 * sq + (2.0 + 3.0 * y) * np.log((sq + 1.0) / (sq - 1.0)))
+        alpha_b = 2.07 * k_eq * s * (1.0 + R_d) ** -0.75 * G
+        beta_node = 8.41 * wm ** 0.435
+        s_tilde = s / (1.0 + (beta_node / (k * s)) ** 3) ** (1.0 / 3.0)
+        beta_b = 0.5 + fb + (3.0 - 2.0 * fb) * np.sqrt((17.2 * wm) ** 2 + 1.0)
+        Tb = ((T0(k, 1.0, 1.0) / (1.0 + (k * s / 5.2) ** 2)
+               + alpha_b / (1.0 + (beta_b / (k * s)) ** 3) * np.exp(-(k / k_silk) ** 1.4))
+              * np.sinc(k * s_tilde / np.pi))
+        return fb * Tb + fc * Tc
+
+    def P_lin_approx(self, ks, zs, type="eisenhu_osc"):
+        """Primordial power x growth^2 x T^2 (hmvec/cosmology.py:391-402)."""
+        zs = np.atleast_1d(zs)
+        ks = np.asarray(ks)
+        tk = self.Tk(ks, type=type)[None, :]
+        Dz = self.D_growth(1 / (1 + zs), type="anorm")[:, None]
+        kp, ns = self.params["pivot_scalar"], self.params["ns"]
+        omh2 = ((self.params["omch2"] + self.params["ombh2"]) * 100 ** 2.0
+                + self.get_Omega_nu() * self.params["H0"] ** 2.0)
+        kfac = (ks / kp) ** (ns - 1.0) * ks
+        pref = 8 * np.pi ** 2 * self.params["As"] / 25.0 / omh2 ** 2.0 * cspeed ** 4.0
+        return pref * kfac[None, :] * Dz ** 2.0 * tk ** 2.0
+
+    def P_lin(self, ks, zs, knorm=1e-4, kmax=None):
+        raise NotImplementedError("accuracy='medium' needs a CAMB P(k) provider (SURVEY §8f N3)")
+
+    P_lin_slow = P_lin
+
+    def _get_matter_power(self, zs, ks, nonlinear=False):
+        raise NotImplementedError("CAMB matter power is outside the analytic provider (SURVEY §8f N3)")
+
+    # ------------------------------------------------------------------ sigma^2 on the GPU
+    def _ctx(self):
+        if getattr(self, "ctx", None) is None:
+            self.ctx = nat.Context(getattr(self, "_device", 0))
+        return self.ctx
+
+    def _sigma2_device(self, R, sPzk, ks_sigma2):
+        """sigma2[z, r] on device from host inputs; returns a DeviceArray (nz, nR)."""
+        ctx = self._ctx()
+        wq = simpson_weights(ks_sigma2) * ks_sigma2 ** 2.0 / 2.0 / np.pi ** 2
+        d_sP, d_k, d_w, d_R = (ctx.upload(a) for a in (sPzk, ks_sigma2, wq, R))
+        out = ctx.empty((sPzk.shape[0], R.size))
+        ctx.call("hmg_sigma2", sPzk.shape[0], R.size, ks_sigma2.size, d_sP.ptr, d_k.ptr, d_w.ptr,
+                 d_R.ptr, float(self.p["Wkr_taylor_switch"]), out.ptr)
+        return out
+
+    def get_sigma2_R(self, R, zs, kmin=None, kmax=None, numks=None, Ws=None, ret_pk=False):
+        """sigma^2(R, z) (hmvec/cosmology.py:245-269).  R: (nR,) or (1,nR,1).  Returns (nz, nR)."""
+        if Ws is not None:
+            raise NotImplementedError("custom windows are not on the device path")
+        zs = np.atleast_1d(zs)
+        R = np.asarray(R, dtype=np.float64).reshape(-1)
+        kmin = self.p["sigma2_kmin"] if kmin is None else kmin
+        kmax = self.p["sigma2_kmax"] if kmax is None else kmax
+        numks = self.p["sigma2_numks"] if numks is None else numks
+        ks_sigma2 = np.geomspace(kmin, kmax, numks)
+        if self.accuracy == "high":
+            self.sPzk = self.P_lin_slow(ks_sigma2, zs, kmax=kmax)
+        elif self.accuracy == "medium":
+            self.sPzk = self.P_lin(ks_sigma2, zs)
+        elif self.accuracy == "low":
+            self.sPzk = self.P_lin_approx(ks_sigma2, zs)
+        self._d_sigma2 = self._sigma2_device(R, self.sPzk, ks_sigma2)
+        if ret_pk:
+            return self._d_sigma2.numpy(), ks_sigma2[None, None, :], self.sPzk[:, None, :]
+        return self._d_sigma2.numpy()

@@ -1,0 +1,1171 @@
+// libhmgrid — MI355X (gfx950 / CDNA4) kernels + C ABI for the halo-model grid hot path.
+// Boundary and reference citations: include/hmgrid.h.  Design notes: DESIGN.md.
+//
+// Everything here is fp64, HBM-bandwidth or fp64-VALU bound; there is no dense
+// contraction on this path, so no MFMA.  Layout is [z][m][k] with k fastest: a wavefront
+// (64 lanes) always walks consecutive k, so every tensor access is a fully coalesced
+// 512 B (or 1 KiB with double2) wave transaction, and per-(z,m) scalars are wave-uniform.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hmgrid.h"
+#include "sici.hpp"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(const char* what, const char* detail, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s: %s (%s:%d)", what, detail, file, line);
+    g_last_error = buf;
+    return 1;
+}
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define FFT_TRY(expr)                                                                   \
+    do {                                                                                \
+        rocfft_status s_ = (expr);                                                      \
+        if (s_ != rocfft_status_success) {                                              \
+            char m_[32];                                                                \
+            snprintf(m_, sizeof(m_), "rocfft status %d", (int)s_);                      \
+            return fail(#expr, m_, __FILE__, __LINE__);                                 \
+        }                                                                               \
+    } while (0)
+#define NCCL_TRY(expr)                                                                  \
+    do {                                                                                \
+        ncclResult_t r_ = (expr);                                                       \
+        if (r_ != ncclSuccess) return fail(#expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+#define REQUIRE(cond, msg)                                                              \
+    do {                                                                                \
+        if (!(cond)) return fail("invalid argument", msg, __FILE__, __LINE__);          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* work = nullptr;
+    size_t work_bytes = 0;
+};
+
+struct hmg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[64] = {};
+    // grow-only scratch arenas (device)
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    std::map<std::pair<int, int>, FftPlan> plans;  // (nxs, batch) -> plan
+    size_t fft_chunk_bytes = 0;                    // 0 = default
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    double* d_barrier = nullptr;
+    int num_cu = 256;
+};
+
+static int rocfft_refcount = 0;
+
+static int ensure_scratch(hmg_ctx* c, int slot, size_t bytes) {
+    if (c->scratch_bytes[slot] >= bytes) return 0;
+    if (c->scratch[slot]) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->scratch[slot]));
+        c->scratch[slot] = nullptr;
+        c->scratch_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    HIP_TRY(hipMalloc(&c->scratch[slot], want));
+    c->scratch_bytes[slot] = want;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+namespace hmg {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+
+// Sum over a 1-D block (blockDim.x multiple of 64, <= 1024).  Result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    const int nw = (blockDim.x + WAVE - 1) >> 6;
+    double r = 0.0;
+    if (w == 0) {
+        r = (lane < nw) ? lds[lane] : 0.0;
+        r = wave_sum(r);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------- K1: sigma^2(z,m) (A2)
+// grid (nm, ceil(nz/ZT)); block 256.  The window depends on (m, k') only, so it is
+// evaluated once per block and reused for ZT redshifts held in registers; nothing of
+// shape (nz,nm,nq) is ever materialised (the reference builds 1.3 GB temporaries).
+constexpr int SIG_ZT = 8;
+__global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
+                                                     const double* __restrict__ sP,
+                                                     const double* __restrict__ kq,
+                                                     const double* __restrict__ wq,
+                                                     const double* __restrict__ R, double tswitch,
+                                                     double* __restrict__ out) {
+    __shared__ double lds[16];
+    const int m = blockIdx.x;
+    const int z0 = blockIdx.y * SIG_ZT;
+    const double r = R[m];
+    double acc[SIG_ZT];
+#pragma unroll
+    for (int i = 0; i < SIG_ZT; ++i) acc[i] = 0.0;
+    for (int j = threadIdx.x; j < nq; j += blockDim.x) {
+        const double kR = kq[j] * r;
+        double w;
+        if (kR < tswitch) {
+            const double xx = kR * kR;
+            w = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
+        } else {
+            double s, c;
+            sincos(kR, &s, &c);
+            w = 3.0 * (s - kR * c) / (kR * kR * kR);
+        }
+        const double a = wq[j] * (w * w);
+#pragma unroll
+        for (int i = 0; i < SIG_ZT; ++i) {
+            const int z = z0 + i;
+            if (z < nz) acc[i] += a * sP[(size_t)z * nq + j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SIG_ZT; ++i) {
+        const double tot = block_sum(acc[i], lds);
+        if (threadIdx.x == 0 && z0 + i < nz) out[(size_t)(z0 + i) * nm + m] = tot;
+    }
+}
+
+// ---------------------------------------------------------------- K2: mass function (A3/A4)
+struct MassFnDev {
+    int mode;
+    double deltac, A, a, p, rho_m0;
+    int uniform;
+    double step;
+};
+
+__device__ __forceinline__ double tinker10_bias(double nu) {
+    const double dc = 1.686;
+    const double y = log10(200.0);
+    const double ey = exp(-pow(4.0 / y, 4.0));
+    const double A = 1.0 + 0.24 * y * ey;
+    const double a = 0.44 * y - 0.88;
+    const double C = 0.019 + 0.107 * y + 0.19 * ey;
+    const double nua = pow(nu, a);
+    return 1.0 - A * nua / (nua + pow(dc, a)) + 0.183 * pow(nu, 1.5) + C * pow(nu, 2.4);
+}
+
+__global__ void massfn_kernel(int nz, int nm, MassFnDev P, const double* __restrict__ s2,
+                              const double* __restrict__ ms, const double* __restrict__ lnm,
+                              const double* __restrict__ tz, double* __restrict__ nzm,
+                              double* __restrict__ bh) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nz * nm) return;
+    const int z = idx / nm, m = idx - z * nm;
+    const double* row = s2 + (size_t)z * nm;
+    const double sig2 = row[m];
+    const double dc = P.deltac;
+    double f, b;
+    if (P.mode == HMG_MF_SHETH_TORMEN) {
+        const double sig = sqrt(sig2);
+        f = P.A * sqrt(2.0 * P.a / M_PI) * (1.0 + pow(sig2 / P.a / (dc * dc), P.p)) * (dc / sig) *
+            exp(-P.a * (dc * dc) / 2.0 / sig2);
+        const double t = P.a * (dc * dc) / sig2;
+        b = 1.0 + (1.0 / dc) * (t - 1.0) + (2.0 * P.p / dc) / (1.0 + pow(t, P.p));
+    } else {
+        const double nu = dc / sqrt(sig2);
+        const double al = tz[z * 5 + 0], be = tz[z * 5 + 1], ph = tz[z * 5 + 2], et = tz[z * 5 + 3],
+                     ga = tz[z * 5 + 4];
+        const double fnu = al * ((1.0 + pow(be * nu, -2.0 * ph)) * pow(nu, 2.0 * et) *
+                                 exp(-ga * (nu * nu) / 2.0));
+        f = nu * fnu;
+        b = tinker10_bias(nu);
+    }
+    // d ln(1/sigma) / d ln m with numpy.gradient's stencils (second order interior,
+    // one-sided first order at the ends; uniform-grid shortcut when numpy would take it)
+    auto L = [&](int i) { return -0.5 * log(row[i]); };
+    double g;
+    if (nm == 1) {
+        g = 0.0;
+    } else if (m == 0) {
+        g = (L(1) - L(0)) / (P.uniform ? P.step : (lnm[1] - lnm[0]));
+    } else if (m == nm - 1) {
+        g = (L(nm - 1) - L(nm - 2)) / (P.uniform ? P.step : (lnm[nm - 1] - lnm[nm - 2]));
+    } else if (P.uniform) {
+        g = (L(m + 1) - L(m - 1)) / (2.0 * P.step);
+    } else {
+        const double d1 = lnm[m] - lnm[m - 1], d2 = lnm[m + 1] - lnm[m];
+        const double ca = -d2 / (d1 * (d1 + d2)), cb = (d2 - d1) / (d1 * d2), cc = d1 / (d2 * (d1 + d2));
+        g = ca * L(m - 1) + cb * L(m) + cc * L(m + 1);
+    }
+    const double mm = ms[m];
+    nzm[idx] = P.rho_m0 * f * g / (mm * mm);
+    bh[idx] = b;
+}
+
+// ---------------------------------------------------------------- A5: c(m,z), rvir(m,z)
+__global__ void halo_structure_kernel(int nz, int nm, const double* __restrict__ ms,
+                                      const double* __restrict__ zs,
+                                      const double* __restrict__ delta,
+                                      const double* __restrict__ rho, double A, double alpha,
+                                      double beta, double h, double* __restrict__ cs,
+                                      double* __restrict__ rv, double* __restrict__ rs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nz * nm) return;
+    const int z = idx / nm, m = idx - z * nm;
+    const double mm = ms[m];
+    const double c = A * pow(h * mm / 2.0e12, alpha) * pow(1.0 + zs[z], beta);
+    const double r = pow(3.0 * mm / 4.0 / M_PI / delta[z] / rho[z], 1.0 / 3.0);
+    cs[idx] = c;
+    rv[idx] = r;
+    rs[idx] = r / c;
+}
+
+// ---------------------------------------------------------------- A7: mass conversion
+__device__ __forceinline__ double fcon(double c) { return log(1.0 + c) - c / (1.0 + c); }
+
+__global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
+                              const double* __restrict__ cs, const double* __restrict__ d1,
+                              double delta2, const double* __restrict__ rho2,
+                              double* __restrict__ m2, double* __restrict__ r2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nz * nm) return;
+    const int z = idx / nm, m = idx - z * nm;
+    const double M1 = ms[m], c1 = cs[idx], ratio = d1[z] / (delta2 * rho2[z]);
+    const double lnM1 = log(M1), MF1 = M1 * (1.0 / fcon(c1));
+    auto resid = [&](double lm2) {
+        const double c2 = c1 * pow(exp(lm2 - lnM1) * ratio, 1.0 / 3.0);
+        return MF1 - exp(lm2) * (1.0 / fcon(c2));
+    };
+    // secant from (x0, x0(1+dx)+dx), dx = eps^0.33 — the starting pair scipy.optimize.newton uses
+    const double dx = 6.8232e-06;
+    double p0 = lnM1, p1 = lnM1 * (1.0 + dx) + (lnM1 >= 0.0 ? dx : -dx);
+    double q0 = resid(p0), q1 = resid(p1);
+    for (int it = 0; it < 60; ++it) {
+        if (q1 == q0) break;
+        const double dp = q1 * (p1 - p0) / (q1 - q0);
+        const double pn = p1 - dp;
+        p0 = p1;
+        q0 = q1;
+        p1 = pn;
+        if (fabs(dp) <= 4.0e-16 * fabs(pn)) break;
+        q1 = resid(p1);
+    }
+    const double M2 = exp(p1);
+    m2[idx] = M2;
+    r2[idx] = pow(3.0 * M2 / 4.0 / M_PI / delta2 / rho2[z], 1.0 / 3.0);
+}
+
+// ---------------------------------------------------------------- K3: analytic NFW (A6)
+// One thread per grid point, k fastest -> coalesced 8 B stores.  ALU-bound (two Si/Ci
+// rational evaluations + five trig calls per 8 bytes written).
+__global__ __launch_bounds__(256) void nfw_kernel(int nm, int nk, const double* __restrict__ cs,
+                                                  const double* __restrict__ rss,
+                                                  const double* __restrict__ zs,
+                                                  const double* __restrict__ ks,
+                                                  double* __restrict__ uk) {
+    const int ktiles = (nk + 255) >> 8;
+    const int row = blockIdx.x / ktiles;  // z*nm + m
+    const int k = (blockIdx.x - row * ktiles) * 256 + threadIdx.x;
+    if (k >= nk) return;
+    const int z = row / nm;
+    const double c = cs[row];
+    const double rs = rss[row];
+    const double mc = log(1.0 + c) - c / (1.0 + c);
+    const double x = ks[k] * rs * (1.0 + zs[z]);
+    const double xc = (1.0 + c) * x;
+    double s1, c1, s2, c2;
+    sincos(x, &s1, &c1);
+    sincos(xc, &s2, &c2);
+    double si1, ci1, si2, ci2;
+    sici_pos(x, s1, c1, si1, ci1);
+    sici_pos(xc, s2, c2, si2, ci2);
+    const double val = (s1 * (si2 - si1) - sin(c * x) / ((1.0 + c) * x) + c1 * (ci2 - ci1)) / mc;
+    uk[(size_t)row * nk + k] = val;
+}
+
+// ---------------------------------------------------------------- A8/X1: row parameters
+struct RowFit { double f[9]; };
+__global__ void rowparams_kernel(int kind, int nz, int nm, const double* __restrict__ m200,
+                                 const double* __restrict__ r200, const double* __restrict__ rvir,
+                                 const double* __restrict__ zs, const double* __restrict__ rhoc,
+                                 const double* __restrict__ hz, RowFit F, double gamma,
+                                 double alpha_const, double pref, double post_pref,
+                                 double* __restrict__ amp, double* __restrict__ xc,
+                                 double* __restrict__ alpha, double* __restrict__ expo,
+                                 double* __restrict__ cmax, double* __restrict__ rscale,
+                                 double* __restrict__ post) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nz * nm) return;
+    const int z = idx / nm;
+    const double M = m200[idx], mr = M / 1.0e14, z1 = 1.0 + zs[z];
+    const double X0 = F.f[0] * pow(mr, F.f[1]) * pow(z1, F.f[2]);
+    const double X1 = F.f[3] * pow(mr, F.f[4]) * pow(z1, F.f[5]);
+    const double X2 = F.f[6] * pow(mr, F.f[7]) * pow(z1, F.f[8]);
+    const double R = r200[idx];
+    if (kind == HMG_PROF_BATTAGLIA_GAS) {
+        // (Ob/Om) rho_c rho0 x^g (1+x^alpha)^(-(beta+g)/alpha),  x = r/(R200c/2)
+        amp[idx] = pref * rhoc[z] * X0;
+        xc[idx] = 1.0;
+        alpha[idx] = X1;
+        expo[idx] = (X2 + gamma) / X1;
+        const double rg = R / 2.0;
+        rscale[idx] = rg;
+        cmax[idx] = rvir[idx] / rg;
+        if (post) post[idx] = 1.0;
+    } else {
+        // eFrac (Ob/Om) 200 M G rho_c / (2 R200) P0 (x/xc)^g (1+(x/xc)^alpha)^(-beta),  x = r/R200c
+        amp[idx] = pref * M * rhoc[z] / (2.0 * R) * X0;
+        xc[idx] = X1;
+        alpha[idx] = alpha_const;
+        expo[idx] = X2;
+        rscale[idx] = R;
+        cmax[idx] = rvir[idx] / R;
+        if (post) post[idx] = post_pref * ((R * R * R) * ((z1 * z1) / hz[z]));
+    }
+}
+
+// ---------------------------------------------------------------- K4: profile integrand (F1)
+// One block per (z,m) row of the current chunk.  Writes the R2C input x*rho*theta and
+// reduces mnorm = trapz(theta rho x^2, x) in the same pass.  Samples beyond the
+// truncation radius are exact zeros and skip the pow evaluations (85 % of a Battaglia
+// row at xmax=20).
+__global__ __launch_bounds__(256) void integrand_kernel(
+    int nxs, int row0, const double* __restrict__ xs, const double* __restrict__ amp,
+    const double* __restrict__ xcs, const double* __restrict__ alphas,
+    const double* __restrict__ expos, double amp_c, double xc_c, double alpha_c, double expo_c,
+    double gamma, const double* __restrict__ cmax, int do_norm, double* __restrict__ fin,
+    double* __restrict__ mnorm) {
+    __shared__ double lds[16];
+    const int lrow = blockIdx.x, row = row0 + lrow;
+    const double A = amp ? amp[row] : amp_c;
+    const double XC = xcs ? xcs[row] : xc_c;
+    const double AL = alphas ? alphas[row] : alpha_c;
+    const double EX = expos ? expos[row] : expo_c;
+    const double cm = cmax[row];
+    double* dst = fin + (size_t)lrow * nxs;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < nxs; j += blockDim.x) {
+        const double x = xs[j];
+        double rho = 0.0;
+        if (!(fabs(x) > cm)) {
+            const double t = x / XC;
+            rho = A * pow(t, gamma) * pow(1.0 + pow(t, AL), -EX);
+        }
+        dst[j] = x * rho;
+        if (do_norm) {
+            // trapezoid weight of sample j on the (uniform but not assumed) x grid
+            const double xl = (j > 0) ? xs[j - 1] : x, xr = (j + 1 < nxs) ? xs[j + 1] : x;
+            acc += 0.5 * (xr - xl) * (rho * (x * x));
+        }
+    }
+    if (do_norm) {
+        const double tot = block_sum(acc, lds);
+        if (threadIdx.x == 0) mnorm[lrow] = tot;
+    } else if (threadIdx.x == 0) {
+        mnorm[lrow] = 1.0;
+    }
+}
+
+// ---------------------------------------------------------------- K5: fused scale + interp (F1 tail, F3)
+// One block per (z,m) row.  The nh = nxs/2 positive-frequency modes of the row,
+//     u_j = -Im(F_j) * step / kt_j / mnorm,
+// are staged once in LDS (20 KB at nxs=5000); threads then walk the target k grid.  The
+// source grid is uniform in k, so the bracket comes from one multiply + a +-1 fix-up
+// against kout_j = kt_j / rss / (1+z) evaluated exactly as the reference does — this is
+// the reference's Python double loop of np.interp (hmvec/fft.py:97-115).
+template <bool STAGE>
+__global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int row0, double step,
+                                                     const double2* __restrict__ F /*[rows][nh+1]*/,
+                                                     const double* __restrict__ kts,
+                                                     const double* __restrict__ mnorm,
+                                                     const double* __restrict__ rss,
+                                                     const double* __restrict__ zs,
+                                                     const double* __restrict__ ks,
+                                                     const double* __restrict__ post,
+                                                     double* __restrict__ out) {
+#pragma clang fp contract(off)
+    extern __shared__ double u[];  // u[j-1] for j = 1..nh
+    const int lrow = blockIdx.x, row = row0 + lrow;
+    const int z = row / nm;
+    const double mn = mnorm[lrow];
+    const double2* Frow = F + (size_t)lrow * (nh + 1);
+    auto mode = [&](int j) {  // u_j, j in 1..nh
+        const double ukt = -Frow[j].y * step;
+        return ukt / kts[j] / mn;
+    };
+    if (STAGE) {
+        for (int j = 1 + threadIdx.x; j <= nh; j += blockDim.x) u[j - 1] = mode(j);
+        __syncthreads();
+    }
+    auto U = [&](int j) { return STAGE ? u[j - 1] : mode(j); };
+    const double rs = rss[row], z1 = 1.0 + zs[z];
+    const double pf = post ? post[row] : 1.0;
+    auto kout = [&](int j) { return kts[j] / rs / z1; };  // j in 1..nh
+    const double k_lo = kout(1), k_hi = kout(nh);
+    const double inv_dk = 1.0 / k_lo;  // kts[j] = j*kts[1] up to rounding
+    double* dst = out + (size_t)row * nk;
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+        const double k = ks[i];
+        double val;
+        if (k < k_lo) {
+            val = U(1);  // left = first positive-k mode
+        } else if (k > k_hi) {
+            val = 0.0;   // right = 0
+        } else if (k == k_hi) {
+            val = U(nh);
+        } else {
+            int j = (int)(k * inv_dk);
+            j = j < 1 ? 1 : (j > nh - 1 ? nh - 1 : j);
+            while (j > 1 && kout(j) > k) --j;
+            while (j < nh - 1 && kout(j + 1) <= k) ++j;
+            const double x0 = kout(j), x1 = kout(j + 1);
+            const double y0 = U(j), y1 = U(j + 1);
+            if (x0 == k) {
+                val = y0;
+            } else {
+                const double slope = (y1 - y0) / (x1 - x0);
+                val = slope * (k - x0) + y0;
+            }
+        }
+        dst[i] = post ? val * pf : val;
+    }
+}
+
+// ---------------------------------------------------------------- K7: HOD (H1-H3)
+struct ShmrSet {
+    double Ms0, Msa, M1, M1a, b0, ba, g0, ga, d0, da;
+};
+__device__ __forceinline__ ShmrSet shmr_for(double z) {
+    // Behroozi+10 table 2, split at z = 0.8 (hmvec/hmvec.py:668-691)
+    if (z <= 0.8) return {10.72, 0.55, 12.35, 0.28, 0.44, 0.18, 1.56, 2.51, 0.57, 0.17};
+    return {11.09, 0.56, 12.27, -0.84, 0.65, 0.31, 1.12, -0.53, 0.56, -0.12};
+}
+__device__ __forceinline__ double shmr_log10mh(double lms, double a, const ShmrSet& s) {
+    const double am1 = a - 1.0;
+    const double lM1 = s.M1 + s.M1a * am1;
+    const double lMs0 = s.Ms0 + s.Msa * am1;
+    const double beta = s.b0 + s.ba * am1;
+    const double gamma = s.g0 + s.ga * am1;
+    const double delta = s.d0 + s.da * am1;
+    const double d = lms - lMs0;
+    return -0.5 + lM1 + beta * d + pow(10.0, delta * d) / (1.0 + pow(10.0, -gamma * d));
+}
+
+constexpr int SHMR_N = 4000;
+struct HodDev {
+    double sig, alphasat, Bsat, betasat, Bcut, betacut;
+    int corr;
+};
+
+// One block per z.  The 4000-point inverse-SHMR table lives in LDS (32 KB).
+__global__ __launch_bounds__(256) void hod_kernel(int nm, HodDev P, const double* __restrict__ zs,
+                                                  const double* __restrict__ ms,
+                                                  const double* __restrict__ lthr,
+                                                  const double* __restrict__ nzm,
+                                                  const double* __restrict__ bh,
+                                                  const double* __restrict__ wm,
+                                                  double* __restrict__ Nc, double* __restrict__ Ns,
+                                                  double* __restrict__ NsNsm1,
+                                                  double* __restrict__ NcNs,
+                                                  double* __restrict__ ngal, double* __restrict__ bg) {
+#pragma clang fp contract(off)
+    __shared__ double mh[SHMR_N];
+    __shared__ double lds[16];
+    const int z = blockIdx.x;
+    const double zz = zs[z], a = 1.0 / (1.0 + zz);
+    const ShmrSet S = shmr_for(zz);
+    const double gstep = 36.0 / (double)(SHMR_N - 1);  // np.linspace(-18,18,4000)
+    auto grid = [&](int j) { return j == SHMR_N - 1 ? 18.0 : (double)j * gstep + (-18.0); };
+    for (int j = threadIdx.x; j < SHMR_N; j += blockDim.x) mh[j] = shmr_log10mh(grid(j), a, S);
+    __syncthreads();
+    const double thr = lthr[z];
+    const double mthr_halo = shmr_log10mh(thr, a, S);
+    const double Msat = 1.0e12 * P.Bsat * pow(10.0, (mthr_halo - 12.0) * P.betasat);
+    const double Mcut = 1.0e12 * P.Bcut * pow(10.0, (mthr_halo - 12.0) * P.betacut);
+    const double denom = sqrt(2.0) * P.sig;
+    double acc_n = 0.0, acc_b = 0.0;
+    for (int m = threadIdx.x; m < nm; m += blockDim.x) {
+        const double lmh = log10(ms[m]);
+        // np.interp(lmh, mh, grid): binary search for mh[j] <= lmh < mh[j+1]
+        double lmstar;
+        if (lmh < mh[0]) {
+            lmstar = grid(0);
+        } else if (lmh >= mh[SHMR_N - 1]) {
+            lmstar = grid(SHMR_N - 1);
+        } else {
+            int lo = 0, hi = SHMR_N - 1;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (mh[mid] <= lmh) lo = mid; else hi = mid;
+            }
+            if (mh[lo] == lmh) {
+                lmstar = grid(lo);
+            } else {
+                const double slope = (grid(lo + 1) - grid(lo)) / (mh[lo + 1] - mh[lo]);
+                lmstar = slope * (lmh - mh[lo]) + grid(lo);
+            }
+        }
+        const double nc = 0.5 * (1.0 - erf((thr - lmstar) / denom));
+        const double mass = pow(10.0, lmh);
+        const double ns = nc * pow(mass / Msat, P.alphasat) * exp(-Mcut / mass);
+        double nn, cn;
+        if (P.corr == 0) {
+            nn = (fabs(nc) <= 1.0e-8) ? 0.0 : (ns * ns) / nc;   // np.isclose(Nc, 0)
+            cn = ns;
+        } else {
+            nn = ns * ns;
+            cn = ns * nc;
+        }
+        const size_t idx = (size_t)z * nm + m;
+        Nc[idx] = nc; Ns[idx] = ns; NsNsm1[idx] = nn; NcNs[idx] = cn;
+        const double t = wm[m] * (nzm[idx] * (nc + ns));
+        acc_n += t;
+        acc_b += t * bh[idx];
+    }
+    const double tn = block_sum(acc_n, lds);
+    const double tb = block_sum(acc_b, lds);
+    if (threadIdx.x == 0) {
+        ngal[z] = tn;
+        bg[z] = tb / tn;
+    }
+}
+
+// ---------------------------------------------------------------- K6: fused mass integrals (P1-P4)
+// Tracer weights are linear forms in at most NT distinct [z][m][k] tensors:
+//     form_f(z,m,k) = c[f][0](z,m) + sum_t c[f][1+t](z,m) * T_t(z,m,k)
+// f = 0,1: the two factors of the 1-halo integrand (trapz weight and n(z,m) folded into
+// factor 0); f = 2,3: the two 2-halo integrands (weight, n and b_h folded in).
+// power_prep_kernel builds the coefficient table + the k->0 consistency integrals and
+// biases; power_kernel streams every distinct tensor exactly once.
+constexpr int PW_NF = 4;
+constexpr int PW_MAXT = 4;
+
+struct TracerDev {
+    int kind;
+    int t_prof, t_cprof;  // slots in the distinct-tensor list, -1 = none
+    const double *Nc, *Ns, *NcNs, *NsNsm1, *ngal, *bias_override;
+};
+struct PowerPrep {
+    TracerDev a, b;
+    int nt;
+    double rho_m0;
+};
+
+// Linear form of one tracer's 2-halo weight (also its 1-halo factor in the generic case).
+__device__ __forceinline__ void tracer_form(const TracerDev& T, size_t idx, int z, double mass,
+                                            double rho_m0, double* c /*[1+PW_MAXT]*/,
+                                            double& lowk) {
+    for (int i = 0; i <= PW_MAXT; ++i) c[i] = 0.0;
+    if (T.kind == HMG_TRACER_MATTER) {
+        c[1 + T.t_prof] = mass / rho_m0;
+        lowk = mass / rho_m0;
+    } else if (T.kind == HMG_TRACER_PRESSURE) {
+        c[1 + T.t_prof] = 1.0;
+        lowk = 0.0;
+    } else {
+        const double ng = T.ngal[z], nc = T.Nc[idx], ns = T.Ns[idx];
+        if (T.t_cprof >= 0) c[1 + T.t_cprof] += nc / ng; else c[0] += nc / ng;
+        c[1 + T.t_prof] += ns / ng;
+        lowk = (nc + ns) / ng;
+    }
+}
+
+// grid nz blocks, 256 threads; coef layout [z][m][PW_NF][1+nt]; side[z][4] = {bA, CA, bB, CB}
+__global__ __launch_bounds__(256) void power_prep_kernel(int nm, PowerPrep Q,
+                                                         const double* __restrict__ nzm,
+                                                         const double* __restrict__ bh,
+                                                         const double* __restrict__ ms,
+                                                         const double* __restrict__ wm,
+                                                         double* __restrict__ coef,
+                                                         double* __restrict__ side) {
+    __shared__ double lds[16];
+    const int z = blockIdx.x;
+    const int nc1 = 1 + Q.nt;
+    double accCA = 0.0, accCB = 0.0, accBA = 0.0, accBB = 0.0;
+    for (int m = threadIdx.x; m < nm; m += blockDim.x) {
+        const size_t idx = (size_t)z * nm + m;
+        const double mass = ms[m];
+        const double wn = wm[m] * nzm[idx];
+        const double wnb = wn * bh[idx];
+        double fa[1 + PW_MAXT], fb[1 + PW_MAXT], x1[1 + PW_MAXT], x2[1 + PW_MAXT];
+        double lowA, lowB;
+        tracer_form(Q.a, idx, z, mass, Q.rho_m0, fa, lowA);
+        tracer_form(Q.b, idx, z, mass, Q.rho_m0, fb, lowB);
+        if (Q.a.kind == HMG_TRACER_HOD && Q.b.kind == HMG_TRACER_HOD) {
+            // (2 u_c u_s <NcNs> + <Ns(Ns-1)> u_s^2)/ngal^2 of the FIRST name (hmvec.py:510-511)
+            for (int i = 0; i <= PW_MAXT; ++i) x1[i] = x2[i] = 0.0;
+            const double ng = Q.a.ngal[z], ng2 = ng * ng;
+            x1[1 + Q.a.t_prof] = 1.0;
+            const double cc = 2.0 * Q.a.NcNs[idx] / ng2;
+            if (Q.a.t_cprof >= 0) x2[1 + Q.a.t_cprof] += cc; else x2[0] += cc;
+            x2[1 + Q.a.t_prof] += Q.a.NsNsm1[idx] / ng2;
+        } else if (Q.a.kind == HMG_TRACER_PRESSURE && Q.b.kind == HMG_TRACER_PRESSURE) {
+            // pk_a**2 — first name only (hmvec.py:512-513)
+            for (int i = 0; i <= PW_MAXT; ++i) { x1[i] = fa[i]; x2[i] = fa[i]; }
+        } else {
+            for (int i = 0; i <= PW_MAXT; ++i) { x1[i] = fa[i]; x2[i] = fb[i]; }
+        }
+        double* c = coef + idx * (size_t)(PW_NF * nc1);
+        for (int i = 0; i < nc1; ++i) {
+            c[0 * nc1 + i] = wn * x1[i];
+            c[1 * nc1 + i] = x2[i];
+            c[2 * nc1 + i] = wnb * fa[i];
+            c[3 * nc1 + i] = wnb * fb[i];
+        }
+        accCA += wnb * lowA;
+        accCB += wnb * lowB;
+        if (Q.a.kind == HMG_TRACER_HOD) accBA += wnb * (Q.a.Nc[idx] + Q.a.Ns[idx]);
+        if (Q.b.kind == HMG_TRACER_HOD) accBB += wnb * (Q.b.Nc[idx] + Q.b.Ns[idx]);
+    }
+    const double CA = block_sum(accCA, lds), CB = block_sum(accCB, lds);
+    const double BA = block_sum(accBA, lds), BB = block_sum(accBB, lds);
+    if (threadIdx.x == 0) {
+        auto bias = [&](const TracerDev& T, double hodsum) {
+            if (T.bias_override) return T.bias_override[z];
+            if (T.kind == HMG_TRACER_MATTER) return 1.0;
+            if (T.kind == HMG_TRACER_PRESSURE) return 0.0;
+            return hodsum / T.ngal[z];
+        };
+        side[z * 4 + 0] = bias(Q.a, BA);
+        side[z * 4 + 1] = CA;
+        side[z * 4 + 2] = bias(Q.b, BB);
+        side[z * 4 + 3] = CB;
+    }
+}
+
+struct PowerArgs {
+    const double* tens[PW_MAXT];
+    const double* coef;
+    const double* side;
+    const double* ks;
+    const double* Pzk;
+    double* P1h;
+    double* P2h;
+    double kstar;
+    int nm, nk;
+};
+
+template <int V> struct VecT;
+template <> struct VecT<1> { using type = double; };
+template <> struct VecT<2> { using type = double2; };
+
+template <int V> __device__ __forceinline__ double vget(const typename VecT<V>::type& v, int i);
+template <> __device__ __forceinline__ double vget<1>(const double& v, int) { return v; }
+template <> __device__ __forceinline__ double vget<2>(const double2& v, int i) { return i ? v.y : v.x; }
+
+// grid (ceil(nk/(64 V)), nz); block 64*MS threads: lane -> V consecutive k, wave -> an
+// interleaved slice of the mass axis.  Each wave streams 512 B*V per tensor per mass bin
+// (fully coalesced), partial sums over the MS slices are combined through LDS.
+template <int NT, int V>
+__global__ __launch_bounds__(1024) void power_kernel(PowerArgs A) {
+    extern __shared__ double red[];  // [MS][3][V][64]
+    using vec_t = typename VecT<V>::type;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int MS = blockDim.x >> 6;
+    const int z = blockIdx.y;
+    const int k0 = (blockIdx.x * 64 + lane) * V;
+    const bool live = k0 < A.nk;  // nk % V == 0 is guaranteed by the launcher
+    constexpr int NC1 = 1 + NT;
+    double a1[V], aA[V], aB[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) a1[v] = aA[v] = aB[v] = 0.0;
+    const size_t zrow = (size_t)z * A.nm;
+#pragma unroll 4
+    for (int m = wv; m < A.nm; m += MS) {
+        const double* __restrict__ c = A.coef + (zrow + m) * (size_t)(PW_NF * NC1);
+        vec_t t[NT];
+        const size_t off = (zrow + m) * (size_t)A.nk + k0;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (live) t[i] = *reinterpret_cast<const vec_t*>(A.tens[i] + off);
+            else t[i] = vec_t{};
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            double f0 = c[0 * NC1], f1 = c[1 * NC1], f2 = c[2 * NC1], f3 = c[3 * NC1];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const double tv = vget<V>(t[i], v);
+                f0 += c[0 * NC1 + 1 + i] * tv;
+                f1 += c[1 * NC1 + 1 + i] * tv;
+                f2 += c[2 * NC1 + 1 + i] * tv;
+                f3 += c[3 * NC1 + 1 + i] * tv;
+            }
+            a1[v] += f0 * f1;
+            aA[v] += f2;
+            aB[v] += f3;
+        }
+    }
+    // combine the MS mass slices
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        red[((wv * 3 + 0) * V + v) * 64 + lane] = a1[v];
+        red[((wv * 3 + 1) * V + v) * 64 + lane] = aA[v];
+        red[((wv * 3 + 2) * V + v) * 64 + lane] = aB[v];
+    }
+    __syncthreads();
+    if (wv == 0 && live) {
+        const double bA = A.side[z * 4 + 0], CA = A.side[z * 4 + 1];
+        const double bB = A.side[z * 4 + 2], CB = A.side[z * 4 + 3];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            double s1 = 0.0, sA = 0.0, sB = 0.0;
+            for (int w = 0; w < MS; ++w) {
+                s1 += red[((w * 3 + 0) * V + v) * 64 + lane];
+                sA += red[((w * 3 + 1) * V + v) * 64 + lane];
+                sB += red[((w * 3 + 2) * V + v) * 64 + lane];
+            }
+            const int k = k0 + v;
+            const size_t o = (size_t)z * A.nk + k;
+            if (A.P1h) {
+                const double q = A.ks[k] / A.kstar;
+                A.P1h[o] = s1 * (1.0 - exp(-(q * q)));
+            }
+            if (A.P2h) A.P2h[o] = A.Pzk[o] * (sA + bA - CA) * (sB + bB - CB);
+        }
+    }
+}
+
+}  // namespace hmg
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace hmg;
+
+static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// (definitions below inherit C linkage from the declarations in hmgrid.h)
+
+int hmg_abi_version(void) { return HMG_ABI_VERSION; }
+const char* hmg_last_error(void) { return g_last_error.c_str(); }
+
+int hmg_ctx_create(int device, hmg_ctx** out) {
+    REQUIRE(out != nullptr, "out is NULL");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    REQUIRE(ndev > 0, "no HIP device visible");
+    REQUIRE(device >= 0 && device < ndev, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hmg_ctx* c = new hmg_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    if (rocfft_refcount++ == 0) FFT_TRY(rocfft_setup());
+    if (const char* s = getenv("HMG_FFT_CHUNK_MB")) c->fft_chunk_bytes = (size_t)atol(s) << 20;
+    *out = c;
+    return 0;
+}
+
+int hmg_ctx_destroy(hmg_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    for (auto& kv : c->plans) {
+        if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
+        if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
+        if (kv.second.work) (void)hipFree(kv.second.work);
+    }
+    for (auto& s : c->scratch) if (s) (void)hipFree(s);
+    if (c->d_barrier) (void)hipFree(c->d_barrier);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    if (--rocfft_refcount == 0) rocfft_cleanup();
+    delete c;
+    return 0;
+}
+
+int hmg_malloc(hmg_ctx* c, size_t bytes, void** d_out) {
+    REQUIRE(c && d_out, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 8));
+    return 0;
+}
+int hmg_free(hmg_ctx* c, void* p) {
+    REQUIRE(c, "NULL ctx");
+    if (!p) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(p));
+    return 0;
+}
+int hmg_memcpy_h2d(hmg_ctx* c, void* d, const void* h, size_t bytes) {
+    REQUIRE(c && d && h, "NULL argument");
+    // pageable source: hipMemcpyAsync stages and returns once the source is consumed
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int hmg_memcpy_d2h(hmg_ctx* c, void* h, const void* d, size_t bytes) {
+    REQUIRE(c && d && h, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int hmg_memcpy_d2d(hmg_ctx* c, void* dst, const void* src, size_t bytes) {
+    REQUIRE(c && dst && src, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int hmg_sync(hmg_ctx* c) {
+    REQUIRE(c, "NULL ctx");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int hmg_event_record(hmg_ctx* c, int slot) {
+    REQUIRE(c && slot >= 0 && slot < 64, "bad event slot");
+    HIP_TRY(hipEventRecord(c->ev[slot], c->stream));
+    return 0;
+}
+int hmg_elapsed_ms(hmg_ctx* c, int s0, int s1, double* ms) {
+    REQUIRE(c && ms && s0 >= 0 && s0 < 64 && s1 >= 0 && s1 < 64, "bad event slot");
+    HIP_TRY(hipEventSynchronize(c->ev[s1]));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, c->ev[s0], c->ev[s1]));
+    *ms = (double)f;
+    return 0;
+}
+
+int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const double* kq,
+               const double* wq, const double* R, double tswitch, double* out) {
+    REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
+    dim3 grid(nm, (nz + SIG_ZT - 1) / SIG_ZT);
+    REQUIRE(grid.y <= 65535, "nz too large");
+    hipLaunchKernelGGL(sigma2_kernel, grid, dim3(256), 0, c->stream, nz, nm, nq, sP, kq, wq, R,
+                       tswitch, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_massfn(hmg_ctx* c, int nz, int nm, const hmg_massfn_params* p, const double* s2,
+               const double* ms, const double* lnms, const double* tz, double* nzm, double* bh) {
+    REQUIRE(c && p && s2 && ms && lnms && nzm && bh, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    REQUIRE(p->mode == HMG_MF_SHETH_TORMEN || p->mode == HMG_MF_TINKER10, "unknown mass function");
+    REQUIRE(p->mode != HMG_MF_TINKER10 || tz, "Tinker mode needs d_tinker_z");
+    MassFnDev P{p->mode, p->deltac, p->st_A, p->st_a, p->st_p, p->rho_m0, p->lnm_uniform, p->lnm_step};
+    hipLaunchKernelGGL(massfn_kernel, grid1d((size_t)nz * nm, 256), dim3(256), 0, c->stream, nz, nm,
+                       P, s2, ms, lnms, tz, nzm, bh);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_halo_structure(hmg_ctx* c, int nz, int nm, const double* ms, const double* zs,
+                       const double* delta, const double* rho, double A, double alpha, double beta,
+                       double h, double* cs, double* rv, double* rs) {
+    REQUIRE(c && ms && zs && delta && rho && cs && rv && rs, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    hipLaunchKernelGGL(halo_structure_kernel, grid1d((size_t)nz * nm, 256), dim3(256), 0, c->stream,
+                       nz, nm, ms, zs, delta, rho, A, alpha, beta, h, cs, rv, rs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_mdelta_convert(hmg_ctx* c, int nz, int nm, const double* ms, const double* cs,
+                       const double* d1, double delta2, const double* rho2, double* m2, double* r2) {
+    REQUIRE(c && ms && cs && d1 && rho2 && m2 && r2, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    hipLaunchKernelGGL(mdelta_kernel, grid1d((size_t)nz * nm, 128), dim3(128), 0, c->stream, nz, nm,
+                       ms, cs, d1, delta2, rho2, m2, r2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const double* rs,
+                     const double* zs, const double* ks, double* uk) {
+    REQUIRE(c && cs && rs && zs && ks && uk, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
+    const size_t blocks = (size_t)nz * nm * ((nk + 255) / 256);
+    REQUIRE(blocks <= 2147483647u, "grid too large");
+    hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, nm, nk, cs, rs, zs, ks, uk);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_profile_rowparams(hmg_ctx* c, int kind, int nz, int nm, const double* m200, const double* r200,
+                          const double* rvir, const double* zs, const double* rhoc, const double* hz,
+                          const double f[9], double gamma, double alpha_const, double pref,
+                          double post_pref, double* amp, double* xc, double* alpha, double* expo,
+                          double* cmax, double* rscale, double* post) {
+    REQUIRE(c && m200 && r200 && rvir && zs && rhoc && f && amp && xc && alpha && expo && cmax && rscale,
+            "NULL argument");
+    REQUIRE(kind == HMG_PROF_BATTAGLIA_GAS || kind == HMG_PROF_BATTAGLIA_PRES, "unknown profile kind");
+    REQUIRE(kind != HMG_PROF_BATTAGLIA_PRES || (hz && post), "pressure needs d_hz and d_post");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    RowFit F;
+    for (int i = 0; i < 9; ++i) F.f[i] = f[i];
+    hipLaunchKernelGGL(rowparams_kernel, grid1d((size_t)nz * nm, 256), dim3(256), 0, c->stream, kind,
+                       nz, nm, m200, r200, rvir, zs, rhoc, hz, F, gamma, alpha_const, pref, post_pref,
+                       amp, xc, alpha, expo, cmax, rscale, post);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int get_plan(hmg_ctx* c, int nxs, int batch, FftPlan** out) {
+    auto key = std::make_pair(nxs, batch);
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) { *out = &it->second; return 0; }
+    FftPlan P;
+    size_t len = (size_t)nxs;
+    FFT_TRY(rocfft_plan_create(&P.plan, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                               rocfft_precision_double, 1, &len, (size_t)batch, nullptr));
+    FFT_TRY(rocfft_plan_get_work_buffer_size(P.plan, &P.work_bytes));
+    FFT_TRY(rocfft_execution_info_create(&P.info));
+    if (P.work_bytes) {
+        HIP_TRY(hipMalloc(&P.work, P.work_bytes));
+        FFT_TRY(rocfft_execution_info_set_work_buffer(P.info, P.work, P.work_bytes));
+    }
+    FFT_TRY(rocfft_execution_info_set_stream(P.info, c->stream));
+    auto res = c->plans.emplace(key, P);
+    *out = &res.first->second;
+    return 0;
+}
+
+int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, const double* xs, const double* kts,
+                    const double* amp, const double* xcs, const double* alpha, const double* expo,
+                    double amp_c, double xc_c, double alpha_c, double expo_c, double gamma,
+                    const double* cmax, const double* rss, const double* zs, const double* ks,
+                    int do_mass_norm, const double* post, double* out) {
+    REQUIRE(c && xs && kts && cmax && rss && zs && ks && out, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
+    REQUIRE(nxs >= 4, "nxs too small");
+    const int nh = nxs / 2;  // rfft output length is nh+1
+    const int rows = nz * nm;
+    // Chunk the batch so integrand + spectrum of a chunk stay inside the 256 MiB Infinity Cache:
+    // the R2C input written by K4 and the spectrum read by K5 then never round-trip through HBM.
+    const size_t per_row = (size_t)nxs * 8 + (size_t)(nh + 1) * 16;
+    size_t budget = c->fft_chunk_bytes ? c->fft_chunk_bytes : ((size_t)160 << 20);
+    int chunk = (int)(budget / per_row);
+    if (chunk < 1) chunk = 1;
+    if (chunk > rows) chunk = rows;
+    if (ensure_scratch(c, 0, (size_t)chunk * nxs * 8)) return 1;
+    if (ensure_scratch(c, 1, (size_t)chunk * (nh + 1) * 16)) return 1;
+    if (ensure_scratch(c, 2, (size_t)chunk * 8)) return 1;
+    double* fin = (double*)c->scratch[0];
+    double2* fout = (double2*)c->scratch[1];
+    double* mnorm = (double*)c->scratch[2];
+    REQUIRE(step > 0.0, "step must be positive");
+    const bool stage = (size_t)nh * sizeof(double) <= 64 * 1024;
+    const size_t lds = stage ? (size_t)nh * sizeof(double) : 0;
+    for (int r0 = 0; r0 < rows; r0 += chunk) {
+        const int nr = rows - r0 < chunk ? rows - r0 : chunk;
+        hipLaunchKernelGGL(integrand_kernel, dim3(nr), dim3(256), 0, c->stream, nxs, r0, xs, amp, xcs,
+                           alpha, expo, amp_c, xc_c, alpha_c, expo_c, gamma, cmax, do_mass_norm, fin, mnorm);
+        HIP_TRY(hipGetLastError());
+        FftPlan* P = nullptr;
+        if (get_plan(c, nxs, nr, &P)) return 1;
+        void* ib[1] = {fin};
+        void* ob[1] = {fout};
+        FFT_TRY(rocfft_execute(P->plan, ib, ob, P->info));
+        if (stage)
+            hipLaunchKernelGGL(interp_kernel<true>, dim3(nr), dim3(256), lds, c->stream, nm, nk, nh, r0, step,
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, post, out);
+        else
+            hipLaunchKernelGGL(interp_kernel<false>, dim3(nr), dim3(256), 0, c->stream, nm, nk, nh, r0, step,
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, post, out);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int hmg_hod(hmg_ctx* c, int nz, int nm, const hmg_hod_params* p, const double* zs, const double* ms,
+            const double* lthr, const double* nzm, const double* bh, const double* wm, double* Nc,
+            double* Ns, double* NsNsm1, double* NcNs, double* ngal, double* bg) {
+    REQUIRE(c && p && zs && ms && lthr && nzm && bh && wm && Nc && Ns && NsNsm1 && NcNs && ngal && bg,
+            "NULL argument");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    REQUIRE(p->corr == 0 || p->corr == 1, "corr must be 0 (max) or 1 (min)");
+    HodDev P{p->sig_log_mstellar, p->alphasat, p->Bsat, p->betasat, p->Bcut, p->betacut, p->corr};
+    hipLaunchKernelGGL(hod_kernel, dim3(nz), dim3(256), 0, c->stream, nm, P, zs, ms, lthr, nzm, bh, wm,
+                       Nc, Ns, NsNsm1, NcNs, ngal, bg);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int tensor_slot(std::vector<const double*>& list, const double* p) {
+    if (!p) return -1;
+    for (size_t i = 0; i < list.size(); ++i)
+        if (list[i] == p) return (int)i;
+    list.push_back(p);
+    return (int)list.size() - 1;
+}
+
+static int fill_tracer(const hmg_tracer* t, std::vector<const double*>& tens, TracerDev* out) {
+    REQUIRE(t->kind == HMG_TRACER_MATTER || t->kind == HMG_TRACER_HOD || t->kind == HMG_TRACER_PRESSURE,
+            "unknown tracer kind");
+    REQUIRE(t->d_prof, "tracer has no profile tensor");
+    out->kind = t->kind;
+    out->t_prof = tensor_slot(tens, t->d_prof);
+    out->t_cprof = (t->kind == HMG_TRACER_HOD) ? tensor_slot(tens, t->d_cprof) : -1;
+    out->Nc = t->d_Nc; out->Ns = t->d_Ns; out->NcNs = t->d_NcNs; out->NsNsm1 = t->d_NsNsm1;
+    out->ngal = t->d_ngal; out->bias_override = t->d_bias_override;
+    if (t->kind == HMG_TRACER_HOD)
+        REQUIRE(t->d_Nc && t->d_Ns && t->d_NcNs && t->d_NsNsm1 && t->d_ngal, "HOD tracer needs Nc,Ns,NcNs,NsNsm1,ngal");
+    return 0;
+}
+
+template <int NT, int V>
+static int launch_power(hmg_ctx* c, const PowerArgs& A, int nz, int ms_split) {
+    const int per_block = 64 * V;
+    dim3 grid((A.nk + per_block - 1) / per_block, nz);
+    const size_t lds = (size_t)ms_split * 3 * V * 64 * sizeof(double);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)power_kernel<NT, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((power_kernel<NT, V>), grid, dim3(64 * ms_split), lds, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hmg_tracer* tb,
+              const double* nzm, const double* bh, const double* ms, const double* wm, const double* ks,
+              const double* Pzk, double rho_m0, double kstar, double* P1h, double* P2h) {
+    REQUIRE(c && ta && tb && nzm && bh && ms && wm && ks, "NULL argument");
+    REQUIRE(P1h || P2h, "no output requested");
+    REQUIRE(!P2h || Pzk, "P2h needs Pzk");
+    REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
+    REQUIRE(nz <= 65535, "nz too large");
+    std::vector<const double*> tens;
+    PowerPrep Q;
+    if (fill_tracer(ta, tens, &Q.a)) return 1;
+    if (fill_tracer(tb, tens, &Q.b)) return 1;
+    Q.nt = (int)tens.size();
+    Q.rho_m0 = rho_m0;
+    REQUIRE(Q.nt >= 1 && Q.nt <= PW_MAXT, "bad tensor count");
+    const int nc1 = 1 + Q.nt;
+    if (ensure_scratch(c, 3, (size_t)nz * nm * PW_NF * nc1 * 8 + (size_t)nz * 4 * 8 + 64)) return 1;
+    double* coef = (double*)c->scratch[3];
+    double* side = coef + (size_t)nz * nm * PW_NF * nc1;
+    hipLaunchKernelGGL(power_prep_kernel, dim3(nz), dim3(256), 0, c->stream, nm, Q, nzm, bh, ms, wm, coef, side);
+    HIP_TRY(hipGetLastError());
+    PowerArgs A;
+    for (int i = 0; i < PW_MAXT; ++i) A.tens[i] = i < Q.nt ? tens[i] : nullptr;
+    A.coef = coef; A.side = side; A.ks = ks; A.Pzk = Pzk; A.P1h = P1h; A.P2h = P2h;
+    A.kstar = kstar; A.nm = nm; A.nk = nk;
+    bool vec2 = (nk % 2 == 0);
+    for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
+    // enough waves to cover the chip: MS mass slices per block
+    const int V = vec2 ? 2 : 1;
+    const long blocks = (long)((nk + 64 * V - 1) / (64 * V)) * nz;
+    int ms_split = 8;
+    if (blocks * 8 < (long)c->num_cu * 16) ms_split = 16;
+    while (ms_split > 1 && ms_split > nm) ms_split >>= 1;
+#define PW_CASE(NT_)                                                      \
+    case NT_:                                                             \
+        return vec2 ? launch_power<NT_, 2>(c, A, nz, ms_split) : launch_power<NT_, 1>(c, A, nz, ms_split);
+    switch (Q.nt) {
+        PW_CASE(1)
+        PW_CASE(2)
+        PW_CASE(3)
+        PW_CASE(4)
+    }
+#undef PW_CASE
+    return fail("hmg_power", "unreachable", __FILE__, __LINE__);
+}
+
+// ---- RCCL ------------------------------------------------------------------------------------
+int hmg_comm_unique_id(char id[HMG_COMM_ID_BYTES]) {
+    REQUIRE(id, "NULL id");
+    static_assert(sizeof(ncclUniqueId) <= HMG_COMM_ID_BYTES, "id buffer too small");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    memset(id, 0, HMG_COMM_ID_BYTES);
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+int hmg_comm_init(hmg_ctx* c, const char id[HMG_COMM_ID_BYTES], int rank, int nranks) {
+    REQUIRE(c && id, "NULL argument");
+    REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank/nranks");
+    REQUIRE(!c->comm, "communicator already initialised");
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    NCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
+    c->comm_rank = rank;
+    c->comm_size = nranks;
+    HIP_TRY(hipMalloc((void**)&c->d_barrier, 64));
+    HIP_TRY(hipMemset(c->d_barrier, 0, 64));
+    return 0;
+}
+int hmg_comm_allgather(hmg_ctx* c, const double* send, double* recv, size_t count) {
+    REQUIRE(c && send && recv, "NULL argument");
+    if (!c->comm) {  // single rank without a communicator: plain copy
+        if (send != recv) HIP_TRY(hipMemcpyAsync(recv, send, count * 8, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    NCCL_TRY(ncclAllGather(send, recv, count, ncclDouble, c->comm, c->stream));
+    return 0;
+}
+int hmg_comm_allgather_multi(hmg_ctx* c, int n, const double* const* send, double* const* recv,
+                             size_t count) {
+    REQUIRE(c && send && recv && n >= 0, "bad argument");
+    if (!c->comm) {
+        for (int i = 0; i < n; ++i)
+            if (send[i] != recv[i])
+                HIP_TRY(hipMemcpyAsync(recv[i], send[i], count * 8, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        ncclResult_t r = ncclAllGather(send[i], recv[i], count, ncclDouble, c->comm, c->stream);
+        if (r != ncclSuccess) {
+            ncclGroupEnd();
+            return fail("ncclAllGather", ncclGetErrorString(r), __FILE__, __LINE__);
+        }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+}
+int hmg_comm_barrier(hmg_ctx* c) {
+    REQUIRE(c, "NULL ctx");
+    if (c->comm) NCCL_TRY(ncclAllReduce(c->d_barrier, c->d_barrier, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int hmg_comm_destroy(hmg_ctx* c) {
+    REQUIRE(c, "NULL ctx");
+    if (c->comm) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        NCCL_TRY(ncclCommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    return 0;
+}
+

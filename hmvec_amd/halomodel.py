@@ -1,0 +1,623 @@
+"""``HaloModel`` — the drop-in boundary of the hot path (hmvec/hmvec.py:75-572).
+
+Same constructor, ``add_*`` and ``get_power_*`` surface, argument meaning, error types
+and stdout messages as the reference class, but every array lives in HBM and every
+stage is a HIP kernel behind the C ABI in ``include/hmgrid.h``.  Host Python here only
+wires pointers and scalars.  There is no CPU fallback.
+
+State mirrors the reference: ``uk_profiles`` / ``pk_profiles`` map name -> (nz,nm,nk)
+array, ``hods`` maps name -> dict, plus ``sigma2``, ``nzm``, ``bh``, ``Pzk``.  Reads of
+those return numpy arrays (copied from the device on first access, then cached);
+assigning a numpy array to ``uk_profiles[name]`` uploads it.
+"""
+import ctypes as C
+import os
+from collections.abc import MutableMapping
+
+import numpy as np
+import scipy.constants as constants
+
+from . import _native as nat
+from .cosmology import Cosmology
+from .params import battaglia_defaults, default_params
+from .quadrature import gradient_is_uniform, trapz_weights
+
+_trapz = getattr(np, "trapezoid", None) or np.trapz
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def _tinker_alpha_table():
+    """alpha(z) normalisation table of Tinker+10 f(nu) (values of the table the
+    reference ships as hmvec/data/alpha_consistency.txt, read at hmvec/tinker.py:64-66)."""
+    with np.load(os.path.join(_DATA, "tinker10_alpha_of_z.npz")) as f:
+        return f["z"], f["alpha"]
+
+
+class DeviceDict(MutableMapping):
+    """name -> DeviceArray with numpy reads (lazy D2H, cached) and numpy writes (H2D)."""
+
+    def __init__(self, ctx_getter):
+        self._ctx_getter = ctx_getter
+        self._dev = {}
+        self._host = {}
+
+    def dev(self, name):
+        return self._dev[name]
+
+    def set_dev(self, name, darr):
+        self._dev[name] = darr
+        self._host.pop(name, None)
+
+    def __getitem__(self, name):
+        if name not in self._host:
+            self._host[name] = self._dev[name].numpy()
+        return self._host[name]
+
+    def __setitem__(self, name, value):
+        if isinstance(value, nat.DeviceArray):
+            self.set_dev(name, value)
+        else:
+            self.set_dev(name, self._ctx_getter().upload(np.asarray(value, dtype=np.float64)))
+
+    def __delitem__(self, name):
+        del self._dev[name]
+        self._host.pop(name, None)
+
+    def __iter__(self):
+        return iter(self._dev)
+
+    def __len__(self):
+        return len(self._dev)
+
+
+class HodEntry(MutableMapping):
+    """``hods[name]`` — same keys as the reference (hmvec/hmvec.py:452-460); array values
+    are fetched from the device on first read."""
+
+    _ARR = ("Nc", "Ns", "NsNsm1", "NcNs", "ngal", "bg")
+
+    def __init__(self, dev, meta):
+        self.dev = dev          # key -> DeviceArray
+        self._vals = dict(meta)  # python-side values
+
+    def __getitem__(self, k):
+        if k not in self._vals:
+            self._vals[k] = self.dev[k].numpy()
+        return self._vals[k]
+
+    def __setitem__(self, k, v):
+        self._vals[k] = v
+
+    def __delitem__(self, k):
+        self._vals.pop(k, None)
+        self.dev.pop(k, None)
+
+    def __iter__(self):
+        seen = list(self.dev) + [k for k in self._vals if k not in self.dev]
+        return iter(seen)
+
+    def __len__(self):
+        return len(set(self.dev) | set(self._vals))
+
+
+def duffy_concentration(m, z, A=None, alpha=None, beta=None, h=None):
+    """hmvec/hmvec.py:68-73 (host helper kept for API parity)."""
+    A = default_params["duffy_A_mean"] if A is None else A
+    alpha = default_params["duffy_alpha_mean"] if alpha is None else alpha
+    beta = default_params["duffy_beta_mean"] if beta is None else beta
+    h = default_params["H0"] / 100.0 if h is None else h
+    return A * ((h * m / 2.0e12) ** alpha) * (1 + z) ** beta
+
+
+def R_from_M(M, rho, delta):
+    """hmvec/hmvec.py:627-628."""
+    return (3.0 * M / 4.0 / np.pi / delta / rho) ** (1.0 / 3.0)
+
+
+class HaloModel(Cosmology):
+    def __init__(self, zs, ks, ms=None, params={}, mass_function="sheth-torman",
+                 halofit=None, mdef="vir", nfw_numeric=False, skip_nfw=False, accuracy="medium",
+                 engine="camb", *, device=0, ctx=None, background=None):
+        self.zs = np.asarray(zs, dtype=np.float64)
+        self.ks = np.asarray(ks, dtype=np.float64)
+        self._device = device
+        self.ctx = ctx
+        Cosmology.__init__(self, params, halofit, engine=engine, accuracy=accuracy, background=background)
+
+        self.mdef = mdef
+        self.mode = mass_function
+        self.hods = {}
+        self._dcache = {}
+
+        self.uk_profiles = DeviceDict(self._ctx)
+        self.pk_profiles = DeviceDict(self._ctx)
+
+        if ms is not None:
+            self.ms = np.asarray(ms, dtype=np.float64)
+            self.init_mass_function(self.ms)
+
+        if not skip_nfw:
+            self.add_nfw_profile("nfw", numeric=nfw_numeric)
+
+    # ------------------------------------------------------------------ cosmology inputs
+    def _init_cosmology(self, params, halofit):
+        """hmvec/hmvec.py:96-102."""
+        Cosmology._init_cosmology(self, params, halofit)
+        if self.accuracy == "low":
+            self.Pzk = self.P_lin_approx(self.ks, self.zs)
+        else:
+            self.Pzk = self._get_matter_power(self.zs, self.ks, nonlinear=False)
+        if halofit is not None:
+            self.nPzk = self._get_matter_power(self.zs, self.ks, nonlinear=True)
+
+    def deltav(self, z):
+        """Bryan & Norman virial overdensity (hmvec/hmvec.py:105-109)."""
+        x = self.omz(z) - 1.0
+        return 18.0 * np.pi ** 2.0 + 82.0 * x - 39.0 * x ** 2.0
+
+    def _mdef_delta_rho(self):
+        """(delta[z], rho[z]) of the halo mass definition (hmvec/hmvec.py:111-115)."""
+        if self.mdef == "vir":
+            return self.deltav(self.zs), self.rho_critical_z(self.zs)
+        if self.mdef == "mean":
+            return 200.0 + 0.0 * self.zs, self.rho_matter_z(self.zs)
+        raise NotImplementedError(self.mdef)
+
+    def rvir(self, m, z):
+        """Host helper with the reference's signature (hmvec/hmvec.py:111-115)."""
+        if self.mdef == "vir":
+            return R_from_M(m, self.rho_critical_z(z), delta=self.deltav(z))
+        elif self.mdef == "mean":
+            return R_from_M(m, self.rho_matter_z(z), delta=200.0)
+
+    def R_of_m(self, ms):
+        return R_from_M(ms, self.rho_matter_z(0), delta=1.0)
+
+    # ------------------------------------------------------------------ device plumbing
+    def _dev(self, key, builder):
+        if key not in self._dcache:
+            self._dcache[key] = self._ctx().upload(builder())
+        return self._dcache[key]
+
+    @property
+    def _nz(self):
+        return self.zs.size
+
+    @property
+    def _nm(self):
+        return self.ms.size
+
+    @property
+    def _nk(self):
+        return self.ks.size
+
+    def _d_zs(self):
+        return self._dev("zs", lambda: self.zs)
+
+    def _d_ks(self):
+        return self._dev("ks", lambda: self.ks)
+
+    def _d_ms(self):
+        return self._dev("ms", lambda: self.ms)
+
+    def _d_wm(self):
+        return self._dev("wm", lambda: trapz_weights(self.ms))
+
+    def _d_Pzk(self):
+        return self._dev("Pzk", lambda: self.Pzk)
+
+    def _lazy_host(self, name):
+        h = "_h_" + name
+        if getattr(self, h, None) is None:
+            setattr(self, h, getattr(self, "_d_" + name).numpy())
+        return getattr(self, h)
+
+    sigma2 = property(lambda self: self._lazy_host("sigma2"))
+    nzm = property(lambda self: self._lazy_host("nzm"))
+    bh = property(lambda self: self._lazy_host("bh"))
+
+    # ------------------------------------------------------------------ mass function
+    def get_sigma2(self):
+        """hmvec/hmvec.py:121-124 — evaluated by hmg_sigma2."""
+        R = self.R_of_m(self.ms)
+        self.get_sigma2_R(R, self.zs)
+        return self._d_sigma2.numpy()
+
+    def _tinker_z_params(self):
+        """Per-z scalars of Tinker+10 f(nu) (hmvec/tinker.py:53-66): z clamp with the
+        heaviside(.,0) quirk (z == 3 -> 0, z > 3 -> 3) and alpha(z) from the table."""
+        zs = self.zs
+        zc = zs * np.heaviside(3 - zs, 0) + 3 * np.heaviside(zs - 3, 0)
+        tz, ta = _tinker_alpha_table()
+        if np.any(zc < tz[0]) or np.any(zc > tz[-1]):
+            raise ValueError("A value in x_new is outside the interpolation range.")
+        alpha = np.interp(zc, tz, ta)
+        beta = 0.589 * (1 + zc) ** 0.20
+        phi = -0.729 * (1 + zc) ** (-0.08)
+        eta = -0.243 * (1 + zc) ** 0.27
+        gamma = 0.864 * (1 + zc) ** (-0.01)
+        return np.stack([alpha, beta, phi, eta, gamma], axis=1)
+
+    def init_mass_function(self, ms):
+        """sigma2, n(z,m), b(z,m), c(z,m), rvir(z,m) on the device (hmvec/hmvec.py:127-185)."""
+        self.ms = np.asarray(ms, dtype=np.float64)
+        if self.mode not in ("sheth-torman", "tinker"):
+            raise NotImplementedError
+        if self.mdef not in ("vir", "mean"):
+            raise NotImplementedError
+        ctx = self._ctx()
+        nz, nm = self._nz, self._nm
+        self._h_sigma2 = self._h_nzm = self._h_bh = None
+        self._dcache.pop("ms", None)
+        self._dcache.pop("wm", None)
+        self._dcache.pop("m200c", None)
+        # sigma^2
+        R = self.R_of_m(self.ms)
+        self.get_sigma2_R(R, self.zs)          # sets self._d_sigma2 (and self.sPzk)
+        self._h_sigma2 = None
+        # n(z,m), b(z,m)
+        lnm = np.log(self.ms)
+        uniform, step = gradient_is_uniform(lnm)
+        par = nat.MassFnParams(
+            mode=nat.MF_SHETH_TORMEN if self.mode == "sheth-torman" else nat.MF_TINKER10,
+            deltac=self.p["st_deltac"], st_A=self.p["st_A"], st_a=self.p["st_a"], st_p=self.p["st_p"],
+            rho_m0=float(self.rho_matter_z(0)[0]), lnm_uniform=int(uniform), lnm_step=step)
+        d_lnm = ctx.upload(lnm)
+        d_tz = ctx.upload(self._tinker_z_params()) if self.mode == "tinker" else None
+        self._d_nzm, self._d_bh = ctx.empty((nz, nm)), ctx.empty((nz, nm))
+        ctx.call("hmg_massfn", nz, nm, C.byref(par), self._d_sigma2.ptr, self._d_ms().ptr, d_lnm.ptr,
+                 nat.ptr(d_tz), self._d_nzm.ptr, self._d_bh.ptr)
+        # c(z,m), rvir(z,m), rs(z,m)
+        sfx = self.mdef
+        delta, rho = self._mdef_delta_rho()
+        d_delta, d_rho = ctx.upload(delta), ctx.upload(rho)
+        self._d_cs, self._d_rvir, self._d_rs = (ctx.empty((nz, nm)) for _ in range(3))
+        ctx.call("hmg_halo_structure", nz, nm, self._d_ms().ptr, self._d_zs().ptr, d_delta.ptr, d_rho.ptr,
+                 float(self.p["duffy_A_" + sfx]), float(self.p["duffy_alpha_" + sfx]),
+                 float(self.p["duffy_beta_" + sfx]), float(self.h),
+                 self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr)
+        ctx.sync()   # temporaries (d_lnm, d_tz, d_delta, d_rho) may now be released
+
+    def get_fsigmaz(self):
+        raise NotImplementedError("fused into hmg_massfn; read .nzm / .bh")
+
+    def get_bh(self):
+        return self.bh
+
+    def get_nzm(self):
+        return self.nzm
+
+    def concentration(self, mode="duffy"):
+        """hmvec/hmvec.py:163-176."""
+        if mode != "duffy":
+            raise NotImplementedError
+        return self._d_cs.numpy()
+
+    # ------------------------------------------------------------------ profiles
+    def _m200c(self):
+        """(m200c, r200c) on the device (hmvec/hmvec.py:216-225)."""
+        if "m200c" not in self._dcache:
+            ctx = self._ctx()
+            nz, nm = self._nz, self._nm
+            rhoc = self.rho_critical_z(self.zs)
+            delta, rho = self._mdef_delta_rho()
+            d1 = ctx.upload(rho * delta if self.mdef == "vir" else rho * 200.0)
+            d_rhoc = self._dev("rhocz", lambda: rhoc)
+            m2, r2 = ctx.empty((nz, nm)), ctx.empty((nz, nm))
+            ctx.call("hmg_mdelta_convert", nz, nm, self._d_ms().ptr, self._d_cs.ptr, d1.ptr, 200.0,
+                     d_rhoc.ptr, m2.ptr, r2.ptr)
+            ctx.sync()
+            self._dcache["m200c"] = (m2, r2)
+        return self._dcache["m200c"]
+
+    def _fft_grids(self, xmax, nxs):
+        """x grid and FFT wavenumber grid exactly as hmvec/fft.py:45-50,73 build them."""
+        key = ("fftgrid", float(xmax), int(nxs))
+        if key not in self._dcache:
+            xs = np.linspace(0.0, xmax, nxs + 1)[1:]
+            step = (xs[-1] - xs[0]) / xs.size
+            kts = np.fft.rfftfreq(xs.size, step) * 2 * np.pi
+            ctx = self._ctx()
+            self._dcache[key] = (ctx.upload(xs), ctx.upload(kts), float(step))
+        return self._dcache[key]
+
+    def _profile_fft(self, nxs, xmax, rowp, consts, gamma, d_cmax, d_rss, do_mass_norm, d_post=None):
+        ctx = self._ctx()
+        nz, nm, nk = self._nz, self._nm, self._nk
+        d_xs, d_kts, step = self._fft_grids(xmax, nxs)
+        out = ctx.empty((nz, nm, nk))
+        amp, xc, alpha, expo = rowp
+        ctx.call("hmg_profile_fft", nz, nm, nk, int(nxs), step, d_xs.ptr, d_kts.ptr,
+                 nat.ptr(amp), nat.ptr(xc), nat.ptr(alpha), nat.ptr(expo),
+                 float(consts[0]), float(consts[1]), float(consts[2]), float(consts[3]), float(gamma),
+                 d_cmax.ptr, d_rss.ptr, self._d_zs().ptr, self._d_ks().ptr, int(do_mass_norm),
+                 nat.ptr(d_post), out.ptr)
+        return out
+
+    def _battaglia_rowparams(self, kind, fit9, gamma, alpha_const, pref, post_pref):
+        ctx = self._ctx()
+        nz, nm = self._nz, self._nm
+        m200c, r200c = self._m200c()
+        outs = [ctx.empty((nz, nm)) for _ in range(7)]
+        fit = (C.c_double * 9)(*fit9)
+        d_hz = self._dev("hz", lambda: self.h_of_z(self.zs))
+        d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
+        ctx.call("hmg_profile_rowparams", kind, nz, nm, m200c.ptr, r200c.ptr, self._d_rvir.ptr,
+                 self._d_zs().ptr, d_rhoc.ptr, d_hz.ptr, C.byref(fit), float(gamma), float(alpha_const),
+                 float(pref), float(post_pref), *[o.ptr for o in outs])
+        return outs
+
+    def add_battaglia_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
+                              ignore_existing=False):
+        """Battaglia+16 gas density profile -> uk_profiles[name] (hmvec/hmvec.py:188-250)."""
+        if not (ignore_existing):
+            assert name not in self.uk_profiles.keys(), "Profile name already exists."
+        assert name != "nfw", "Name nfw is reserved."
+        if nxs is None:
+            nxs = self.p["electron_density_profile_integral_numxs"]
+        if xmax is None:
+            xmax = self.p["electron_density_profile_integral_xmax"]
+        if family is None:
+            family = self.p["battaglia_gas_family"]
+        pparams = {"battaglia_gas_gamma": self.p["battaglia_gas_gamma"]}
+        pparams.update(battaglia_defaults[family])
+        if param_override is not None:
+            print(param_override)
+            for key in param_override.keys():
+                if key == "battaglia_gas_gamma" or key in battaglia_defaults[family]:
+                    pparams[key] = param_override[key]
+        omb = self.p["ombh2"] / self.h ** 2.0
+        gamma = pparams["battaglia_gas_gamma"]
+        fit9 = [pparams[a + b] for a in ("rho0_", "alpha_", "beta_") for b in ("A0", "alpham", "alphaz")]
+        amp, xc, alpha, expo, cmax, rscale, _post = self._battaglia_rowparams(
+            nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0)
+        out = self._profile_fft(nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
+                                cmax, rscale, True)
+        self._ctx().sync()
+        self.uk_profiles.set_dev(name, out)
+
+    def add_battaglia_pres_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
+                                   ignore_existing=False):
+        """Battaglia+12 electron pressure profile -> pk_profiles[name] (hmvec/hmvec.py:252-316)."""
+        if not (ignore_existing):
+            assert name not in self.pk_profiles.keys(), "Profile name already exists."
+        assert name != "nfw", "Name nfw is reserved."
+        if nxs is None:
+            nxs = self.p["electron_pressure_profile_integral_numxs"]
+        if xmax is None:
+            xmax = self.p["electron_pressure_profile_integral_xmax"]
+        if family is None:
+            family = self.p["battaglia_pres_family"]
+        pparams = {"battaglia_pres_gamma": self.p["battaglia_pres_gamma"],
+                   "battaglia_pres_alpha": self.p["battaglia_pres_alpha"]}
+        pparams.update(battaglia_defaults[family])
+        if param_override is not None:
+            for key in param_override.keys():
+                if key in ("battaglia_pres_gamma", "battaglia_pres_alpha") or key in battaglia_defaults[family]:
+                    pparams[key] = param_override[key]
+        omb = self.p["ombh2"] / self.h ** 2.0
+        gamma, alpha = pparams["battaglia_pres_gamma"], pparams["battaglia_pres_alpha"]
+        fit9 = [pparams[a + b] for a in ("P0_", "xc_", "beta_") for b in ("A0", "alpham", "alphaz")]
+        XH = 0.76
+        eFrac = 2.0 * (XH + 1.0) / (5.0 * XH + 3.0)
+        G_newt = constants.G / (default_params["parsec"] * 1e6) ** 3 * default_params["mSun"]
+        pref = eFrac * (omb / self.omm0) * 200 * G_newt
+        sigmaT = constants.physical_constants["Thomson cross section"][0]
+        mElect = constants.physical_constants["electron mass"][0] / default_params["mSun"]
+        post_pref = 4 * np.pi * (sigmaT / (mElect * constants.c ** 2))
+        amp, xc, _alpha, expo, cmax, rscale, post = self._battaglia_rowparams(
+            nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref)
+        out = self._profile_fft(nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
+                                cmax, rscale, False, d_post=post)
+        self._ctx().sync()
+        self.pk_profiles.set_dev(name, out)
+
+    def add_nfw_profile(self, name, numeric=False, nxs=None, xmax=None, ignore_existing=False):
+        """NFW u(k|m,z): analytic Si/Ci or numeric FFT branch (hmvec/hmvec.py:318-355).
+        Returns (ks, uk) like the reference."""
+        if not (ignore_existing):
+            assert name not in self.uk_profiles.keys(), "Profile name already exists."
+        if nxs is None:
+            nxs = self.p["nfw_integral_numxs"]
+        if xmax is None:
+            xmax = self.p["nfw_integral_xmax"]
+        ctx = self._ctx()
+        nz, nm, nk = self._nz, self._nm, self._nk
+        if numeric:
+            # rho = 1/x/(1+x)^2 is the gamma=-1, alpha=1, expo=2 member of the family
+            out = self._profile_fft(nxs, xmax, (None, None, None, None), (1.0, 1.0, 1.0, 2.0), -1.0,
+                                    self._d_cs, self._d_rs, True)
+        else:
+            out = ctx.empty((nz, nm, nk))
+            ctx.call("hmg_nfw_analytic", nz, nm, nk, self._d_cs.ptr, self._d_rs.ptr, self._d_zs().ptr,
+                     self._d_ks().ptr, out.ptr)
+        self.uk_profiles.set_dev(name, out)
+        return self.ks, _LazyArray(self.uk_profiles, name)
+
+    # ------------------------------------------------------------------ HOD
+    _HOD_PARAMS = ["hod_sig_log_mstellar", "hod_bisection_search_min_log10mthresh",
+                   "hod_bisection_search_max_log10mthresh", "hod_bisection_search_rtol",
+                   "hod_bisection_search_warn_iter", "hod_alphasat", "hod_Bsat",
+                   "hod_betasat", "hod_Bcut", "hod_betacut", "hod_A_log10mthresh"]
+
+    def _hod_device(self, log10mstar_thresh, pparams, corr):
+        """One hmg_hod launch; returns dict of DeviceArrays."""
+        ctx = self._ctx()
+        nz, nm = self._nz, self._nm
+        par = nat.HodParams(pparams["hod_sig_log_mstellar"], pparams["hod_alphasat"], pparams["hod_Bsat"],
+                            pparams["hod_betasat"], pparams["hod_Bcut"], pparams["hod_betacut"],
+                            {"max": 0, "min": 1}[corr])
+        d_thr = ctx.upload(log10mstar_thresh)
+        out = {k: ctx.empty((nz, nm)) for k in ("Nc", "Ns", "NsNsm1", "NcNs")}
+        out["ngal"], out["bg"] = ctx.empty((nz,)), ctx.empty((nz,))
+        ctx.call("hmg_hod", nz, nm, C.byref(par), self._d_zs().ptr, self._d_ms().ptr, d_thr.ptr,
+                 self._d_nzm.ptr, self._d_bh.ptr, self._d_wm().ptr, out["Nc"].ptr, out["Ns"].ptr,
+                 out["NsNsm1"].ptr, out["NcNs"].ptr, out["ngal"].ptr, out["bg"].ptr)
+        ctx.sync()
+        return out
+
+    def add_hod(self, name, mthresh=None, ngal=None, corr="max", satellite_profile_name="nfw",
+                central_profile_name=None, ignore_existing=False, param_override=None):
+        """Specify an HOD by stellar-mass threshold or by number density (hmvec/hmvec.py:357-460)."""
+        if not (ignore_existing):
+            assert name not in self.uk_profiles.keys(), "HOD name already used by profile."
+        assert satellite_profile_name in self.uk_profiles.keys(), "No matter profile by that name exists."
+        if central_profile_name is not None:
+            assert central_profile_name in self.uk_profiles.keys(), "No matter profile by that name exists."
+        if not (ignore_existing):
+            assert name not in self.hods.keys(), "HOD with that name already exists."
+        pparams = {ip: self.p[ip] for ip in self._HOD_PARAMS}
+        if param_override is not None:
+            for key in param_override.keys():
+                if key in self._HOD_PARAMS:
+                    pparams[key] = param_override[key]
+                else:
+                    raise ValueError  # not an HOD parameter
+        if corr not in ("max", "min"):
+            raise ValueError(corr)
+
+        if ngal is not None:
+            ngal = np.asarray(ngal)
+            if ngal.size != self.zs.size:
+                raise ValueError("ngal has to be a vector of size self.zs")
+            assert mthresh is None
+            log10mthresh = self._bisect_mthresh(ngal.astype(np.float64), pparams)
+            mthresh = 10 ** (log10mthresh * pparams["hod_A_log10mthresh"])
+        try:
+            assert mthresh.size == self.zs.size
+        except Exception:
+            raise ValueError("mthresh has to be a vector of size self.zs")
+
+        l10 = np.log10(np.asarray(mthresh, dtype=np.float64))
+        dev = self._hod_device(l10, pparams, corr)
+        self.hods[name] = HodEntry(dev, dict(satellite_profile=satellite_profile_name,
+                                             central_profile=central_profile_name,
+                                             log10mthresh=np.log10(mthresh[:, None])))
+
+    def _bisect_mthresh(self, ngal, pparams, full_model=None):
+        """Bisection on log10 mthresh with the reference's GLOBAL stop test over z
+        (hmvec/utils.py:9-42 called at hmvec/hmvec.py:426-433).  Every z keeps bisecting
+        until all z meet rtol, so the answer depends on the whole z vector."""
+        lo = ngal * 0 + pparams["hod_bisection_search_min_log10mthresh"]
+        hi = ngal * 0 + pparams["hod_bisection_search_max_log10mthresh"]
+        rtol = pparams["hod_bisection_search_rtol"]
+        warn_iter = pparams["hod_bisection_search_warn_iter"]
+        mtol, i, warned = np.inf, 0, False
+        while np.any(np.abs(mtol) > rtol):
+            ynow = (lo + hi) / 2.0
+            xnow = self._hod_device(ynow, pparams, "max")["ngal"].numpy()
+            mtol = (xnow - ngal) / ngal
+            lo[mtol > 0] = ynow[mtol > 0]          # "decreasing" relation
+            hi[mtol <= 0] = ynow[mtol <= 0]
+            i += 1
+            if (i > warn_iter) and not (warned):
+                print("WARNING: Bisection search has done more than ", warn_iter, " loops. Still searching...")
+                warned = True
+        print("Bisection search converged in ", i, " iterations.")
+        return ynow
+
+    def get_ngal(self, Nc, Ns):
+        return _trapz(self.nzm * (Nc + Ns), self.ms, axis=-1)
+
+    def get_bg(self, Nc, Ns, ngal):
+        return _trapz(self.nzm * (Nc + Ns) * self.bh, self.ms, axis=-1) / ngal
+
+    # ------------------------------------------------------------------ spectra
+    def _tracer(self, name, order):
+        """Resolve a tracer name to an hmg_tracer.  `order` is the reference's lookup
+        order, which differs between the 1-halo (hods, uk, pk: hmvec.py:516-523) and the
+        2-halo (uk, pk, hods: hmvec.py:537-550) code paths."""
+        for kind in order:
+            if kind == "h" and name in self.hods:
+                hod = self.hods[name]
+                cn = hod["central_profile"]
+                d = hod.dev
+                t = nat.Tracer(nat.TRACER_HOD, self.uk_profiles.dev(hod["satellite_profile"]).ptr,
+                               None if cn is None else self.uk_profiles.dev(cn).ptr,
+                               d["Nc"].ptr, d["Ns"].ptr, d["NcNs"].ptr, d["NsNsm1"].ptr, d["ngal"].ptr, None)
+                return t, "h"
+            if kind == "m" and name in self.uk_profiles:
+                return nat.Tracer(nat.TRACER_MATTER, self.uk_profiles.dev(name).ptr), "m"
+            if kind == "p" and name in self.pk_profiles:
+                return nat.Tracer(nat.TRACER_PRESSURE, self.pk_profiles.dev(name).ptr), "p"
+        raise ValueError
+
+    def _power_launch(self, ta, tb, want1, want2, out1=None, out2=None):
+        ctx = self._ctx()
+        nz, nm, nk = self._nz, self._nm, self._nk
+        d1 = (out1 if out1 is not None else ctx.empty((nz, nk))) if want1 else None
+        d2 = (out2 if out2 is not None else ctx.empty((nz, nk))) if want2 else None
+        ctx.call("hmg_power", nz, nm, nk, C.byref(ta), C.byref(tb), self._d_nzm.ptr, self._d_bh.ptr,
+                 self._d_ms().ptr, self._d_wm().ptr, self._d_ks().ptr, self._d_Pzk().ptr,
+                 float(self.rho_matter_z(0)[0]), float(self.p["kstar_damping"]), nat.ptr(d1), nat.ptr(d2))
+        return d1, d2
+
+    def power_device(self, name, name2=None, b1_in=None, b2_in=None, want=("1h", "2h"), out1=None, out2=None):
+        """Device-resident (P1h, P2h) DeviceArrays of shape (nz, nk) — one fused pass over the
+        profile tensors when the 1-halo and 2-halo code paths resolve the names identically."""
+        name2 = name if name2 is None else name2
+        keep = []
+        want1, want2 = "1h" in want, "2h" in want
+        a1, ka1 = self._tracer(name, "hmp")
+        b1, kb1 = self._tracer(name2, "hmp")
+        a2, ka2 = self._tracer(name, "mph") if want2 else (a1, ka1)
+        b2, kb2 = self._tracer(name2, "mph") if want2 else (b1, kb1)
+        if want2:
+            for nm_ in (name, name2):
+                if self._tracer(nm_, "mph")[1] == "p":
+                    print("Check the consistency relation for tSZ")
+            if b1_in is not None:
+                keep.append(self._ctx().upload(np.asarray(b1_in, dtype=np.float64).reshape(-1)))
+                a2.d_bias_override = keep[-1].ptr
+            if b2_in is not None:
+                n = b1_in.shape[0]     # reference reshapes b2_in with b1_in's length (hmvec.py:561)
+                keep.append(self._ctx().upload(np.asarray(b2_in, dtype=np.float64).reshape((n, 1))))
+                b2.d_bias_override = keep[-1].ptr
+        same = (ka1 == ka2) and (kb1 == kb2)
+        if want1 and want2 and same:
+            d1, d2 = self._power_launch(a2, b2, True, True, out1, out2)
+        else:
+            d1 = self._power_launch(a1, b1, True, False, out1, None)[0] if want1 else None
+            d2 = self._power_launch(a2, b2, False, True, None, out2)[1] if want2 else None
+        if keep:
+            self._ctx().sync()
+        return d1, d2
+
+    def get_power(self, name, name2=None, verbose=False, b1=None, b2=None):
+        """P_1h + P_2h in one pass (hmvec/hmvec.py:500-502)."""
+        d1, d2 = self.power_device(name, name2, b1, b2)
+        if verbose:
+            self._print_consistency(name, name2)
+        return d1.numpy() + d2.numpy()
+
+    def get_power_1halo(self, name="nfw", name2=None):
+        """hmvec/hmvec.py:504-526."""
+        return self.power_device(name, name2, want=("1h",))[0].numpy()
+
+    def get_power_2halo(self, name="nfw", name2=None, verbose=False, b1_in=None, b2_in=None):
+        """hmvec/hmvec.py:528-572."""
+        out = self.power_device(name, name2, b1_in, b2_in, want=("2h",))[1].numpy()
+        if verbose:
+            self._print_consistency(name, name2)
+        return out
+
+    def _print_consistency(self, name, name2):
+        print("Two-halo consistency: verbose integrals are not materialised on the device path "
+              "(%s, %s)" % (name, name2 if name2 is not None else name))
+
+
+class _LazyArray:
+    """Return value of add_nfw_profile's second element: behaves as the ndarray when used."""
+
+    def __init__(self, mapping, name):
+        self._m, self._n = mapping, name
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._m[self._n]
+        return a if dtype is None else a.astype(dtype)
+
+    def __getattr__(self, k):
+        return getattr(self._m[self._n], k)
+
+    def __getitem__(self, idx):
+        return self._m[self._n][idx]

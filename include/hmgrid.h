@@ -1,0 +1,195 @@
+/*
+ * hmgrid.h — C ABI of libhmgrid.so, the MI355X (gfx950) halo-model grid engine.
+ *
+ * The reference (simonsobs/hmvec) is pure Python and has NO FFI/plugin boundary:
+ * its drop-in boundary is the Python class hmvec.HaloModel (hmvec/hmvec.py:75-572).
+ * This header defines the C boundary a maintainer would bind with ctypes underneath
+ * that class (see INTEGRATION.md for the stub).  Each entry point cites the reference
+ * lines it replaces.
+ *
+ * Conventions
+ *  - All numeric data is IEEE fp64.  Grids are C-contiguous [z][m][k], k fastest
+ *    (hmvec/hmvec.py:24-31).
+ *  - Pointers named d_* are DEVICE pointers obtained from hmg_malloc; pointers
+ *    named h_* are host pointers.  No framework types cross this boundary.
+ *  - Every function returns 0 on success, non-zero on failure; the message for the
+ *    calling thread's last failure is returned by hmg_last_error().
+ *  - All work is enqueued on the context's stream; only hmg_memcpy_d2h, hmg_sync,
+ *    hmg_elapsed_ms and hmg_comm_barrier block the host.
+ *  - A context is bound to one GPU and is not thread-safe; use one per GPU/process.
+ */
+#ifndef HMGRID_H
+#define HMGRID_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMG_ABI_VERSION 1
+
+typedef struct hmg_ctx hmg_ctx;
+
+/* ---- lifetime, memory, timing -------------------------------------------------- */
+int         hmg_abi_version(void);
+const char* hmg_last_error(void);
+int hmg_ctx_create(int device, hmg_ctx** out);
+int hmg_ctx_destroy(hmg_ctx* ctx);
+int hmg_malloc(hmg_ctx* ctx, size_t bytes, void** d_out);
+int hmg_free(hmg_ctx* ctx, void* d_ptr);
+int hmg_memcpy_h2d(hmg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int hmg_memcpy_d2h(hmg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* blocks */
+int hmg_memcpy_d2d(hmg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int hmg_sync(hmg_ctx* ctx);
+/* HIP-event stopwatch on the context's stream: slots 0..63. */
+int hmg_event_record(hmg_ctx* ctx, int slot);
+int hmg_elapsed_ms(hmg_ctx* ctx, int slot_start, int slot_stop, double* h_ms);     /* blocks */
+
+/* ---- A2: sigma^2(z, R(m)) ------------------------------------------------------
+ * Replaces Cosmology.get_sigma2_R (hmvec/cosmology.py:245-269) + Wkr (:30-38).
+ *   sigma2[z,m] = sum_j d_wq[j] * sPzk[z,j] * W(kq[j]*R[m])^2
+ * d_wq carries the quadrature weight times k^2/(2 pi^2); the caller builds it from the
+ * irregular-Simpson rule the reference uses (scipy.integrate.simpson, x given).
+ * W is the Fourier top-hat with the Taylor branch for kR < taylor_switch.           */
+int hmg_sigma2(hmg_ctx* ctx, int nz, int nm, int nq,
+               const double* d_sPzk /*[nz][nq]*/, const double* d_kq /*[nq]*/,
+               const double* d_wq /*[nq]*/, const double* d_R /*[nm]*/,
+               double taylor_switch, double* d_sigma2 /*[nz][nm]*/);
+
+/* ---- A3/A4: mass function n(z,m) and halo bias b(z,m) -----------------------------
+ * Replaces get_fsigmaz/get_bh/get_nzm (hmvec/hmvec.py:133-161,178-185) and
+ * tinker.f_nu/bias (hmvec/tinker.py:26-67).                                          */
+#define HMG_MF_SHETH_TORMEN 0
+#define HMG_MF_TINKER10     1
+typedef struct {
+    int    mode;               /* HMG_MF_* */
+    double deltac, st_A, st_a, st_p;
+    double rho_m0;             /* mean matter density today [Msun/Mpc^3] */
+    int    lnm_uniform;        /* np.gradient takes its uniform-spacing branch */
+    double lnm_step;           /* that spacing (only if lnm_uniform) */
+} hmg_massfn_params;
+int hmg_massfn(hmg_ctx* ctx, int nz, int nm, const hmg_massfn_params* h_par,
+               const double* d_sigma2 /*[nz][nm]*/, const double* d_ms /*[nm]*/,
+               const double* d_lnms /*[nm]*/,
+               const double* d_tinker_z /*[nz][5] = alpha,beta,phi,eta,gamma at clamped z; NULL for ST*/,
+               double* d_nzm /*[nz][nm]*/, double* d_bh /*[nz][nm]*/);
+
+/* ---- A5: concentration, virial radius, scale radius -----------------------------------
+ * Replaces duffy_concentration / concentration / rvir (hmvec/hmvec.py:68-73,111-115,163-176).
+ *   c = A (h m / 2e12)^alpha (1+z)^beta ;  rvir = (3 m / (4 pi delta[z] rho[z]))^(1/3) ;
+ *   rs = rvir / c                                                                          */
+int hmg_halo_structure(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const double* d_zs,
+                       const double* d_delta /*[nz]*/, const double* d_rho /*[nz]*/,
+                       double duffy_A, double duffy_alpha, double duffy_beta, double h,
+                       double* d_cs /*[nz][nm]*/, double* d_rvir /*[nz][nm]*/,
+                       double* d_rs /*[nz][nm]*/);
+
+/* ---- A7: mass-definition conversion -------------------------------------------------
+ * Replaces mdelta_from_mdelta (hmvec/hmvec.py:748-798): secant solve in ln M2 of
+ *   M1 F(c1) = M2 F(c2),  c2 = c1 ((M2/M1)(drho1/drho2))^(1/3),  F = 1/(ln(1+c)-c/(1+c)),
+ * drho2[z] = delta2 * rho2[z].  Also returns r2 = (3 M2/(4 pi delta2 rho2))^(1/3)
+ * (hmvec.py:225).                                                                       */
+int hmg_mdelta_convert(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const double* d_cs,
+                       const double* d_drho1 /*[nz]*/, double delta2, const double* d_rho2 /*[nz]*/,
+                       double* d_m2 /*[nz][nm]*/, double* d_r2 /*[nz][nm]*/);
+
+/* ---- A6: analytic NFW u(k|m,z) --------------------------------------------------------
+ * Replaces the Si/Ci branch of add_nfw_profile (hmvec/hmvec.py:346-353); Si/Ci follow
+ * Cephes sici (scipy.special.sici).                                                     */
+int hmg_nfw_analytic(hmg_ctx* ctx, int nz, int nm, int nk, const double* d_cs,
+                     const double* d_rs, const double* d_zs, const double* d_ks,
+                     double* d_uk /*[nz][nm][nk]*/);
+
+/* ---- A8/X1 row parameters of the generalised-NFW integrand ----------------------------
+ * The three radial profiles of the path are one family
+ *     f(x) = amp * (x/xc)^gamma * (1 + (x/xc)^alpha)^(-expo)
+ *  NFW (hmvec.py:744): amp=1, xc=1, gamma=-1, alpha=1, expo=2
+ *  Battaglia gas (hmvec.py:844-860): xc=1, alpha=alpha(m,z), expo=(beta+gamma)/alpha,
+ *      amp=(Ob/Om) rho_c(z) rho0(m,z)
+ *  Battaglia pressure (hmvec.py:906-927): xc=xc(m,z), alpha const, expo=beta(m,z),
+ *      amp = eFrac (Ob/Om) 200 M G rho_c/(2 R200) P0(m,z)
+ * with X(m,z) = A0 (m200c/1e14)^am (1+z)^az (hmvec.py:800-802).
+ * fit[9] = {A0,am,az} x {rho0|P0, alpha|xc, beta}.  Outputs are [nz][nm].  The same launch
+ * also emits the truncation radius cmax = rvir/rscale and rscale (hmvec.py:247-248,311-312)
+ * and, for pressure, the y-conversion factor of hmvec.py:316.                              */
+#define HMG_PROF_BATTAGLIA_GAS  1
+#define HMG_PROF_BATTAGLIA_PRES 2
+int hmg_profile_rowparams(hmg_ctx* ctx, int kind, int nz, int nm, const double* d_m200c,
+                          const double* d_r200c, const double* d_rvir, const double* d_zs,
+                          const double* d_rhocz /*[nz]*/, const double* d_hz /*[nz] H(z) in 1/Mpc, pressure only*/,
+                          const double h_fit[9], double gamma, double alpha_const,
+                          double amp_prefactor, double post_prefactor,
+                          double* d_amp, double* d_xc, double* d_alpha, double* d_expo,
+                          double* d_cmax /* rvir/rscale */, double* d_rscale /* R200c/2 (gas) or R200c (pressure) */,
+                          double* d_post /* pressure: post_prefactor R200c^3 (1+z)^2/H(z); gas: may be NULL */);
+
+/* ---- F1-F3: radial-profile sine transform + per-(z,m) k-interpolation ------------------
+ * Replaces generic_profile_fft / fft_integral / _interp_loop (hmvec/fft.py:35-115),
+ * bug-compatibly (step=(x[-1]-x[0])/N, 0-based DFT phase, left=u[first k>0], right=0,
+ * strict x>cmax truncation).  Any of d_amp/d_xc/d_alpha/d_expo may be NULL meaning the
+ * constant given in *_const.  d_xs [nxs] and d_kts [nxs/2+1] are the x grid
+ * (linspace(0,xmax,nxs+1)[1:]) and the rfftfreq(nxs,fft_step)*2pi grid, built by the caller;
+ * fft_step = (xs[-1]-xs[0])/nxs (hmvec/fft.py:45-47).
+ * out[z,m,k] *= d_post[z,m] if d_post != NULL (pressure prefactor, hmvec.py:316).          */
+int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_step,
+                    const double* d_xs, const double* d_kts,
+                    const double* d_amp, const double* d_xc, const double* d_alpha,
+                    const double* d_expo, double amp_const, double xc_const,
+                    double alpha_const, double expo_const, double gamma,
+                    const double* d_cmax /*[nz][nm]*/, const double* d_rss /*[nz][nm]*/,
+                    const double* d_zs, const double* d_ks, int do_mass_norm,
+                    const double* d_post /*[nz][nm] or NULL*/,
+                    double* d_out /*[nz][nm][nk]*/);
+
+/* ---- H1-H3: HOD occupations ----------------------------------------------------------------
+ * Replaces avg_Nc/avg_Ns/avg_NsNsm1/avg_NcNs, Mstellar_halo/Mhalo_stellar, get_ngal/get_bg
+ * (hmvec/hmvec.py:634-731,462-466,936-957).  corr: 0 = "max", 1 = "min".                       */
+typedef struct {
+    double sig_log_mstellar, alphasat, Bsat, betasat, Bcut, betacut;
+    int    corr;
+} hmg_hod_params;
+int hmg_hod(hmg_ctx* ctx, int nz, int nm, const hmg_hod_params* h_par, const double* d_zs,
+            const double* d_ms, const double* d_log10mstar_thresh /*[nz]*/,
+            const double* d_nzm, const double* d_bh, const double* d_wm /*[nm] trapz weights*/,
+            double* d_Nc, double* d_Ns, double* d_NsNsm1, double* d_NcNs /*[nz][nm] each*/,
+            double* d_ngal /*[nz]*/, double* d_bg /*[nz]*/);
+
+/* ---- P1-P4: fused 1-halo + 2-halo mass integrals ---------------------------------------------
+ * Replaces _get_matter/_get_hod/_get_hod_square/_get_pressure + get_power_1halo +
+ * get_power_2halo (hmvec/hmvec.py:469-572) in ONE pass over the profile tensors:
+ *   P1h[z,k] = trapz_m[n W_a W_b] (1-exp(-(k/kstar)^2))
+ *   P2h[z,k] = Pzk (I_a + b_a - C_a)(I_b + b_b - C_b)
+ * Either output pointer may be NULL.                                                          */
+#define HMG_TRACER_MATTER   0
+#define HMG_TRACER_HOD      1
+#define HMG_TRACER_PRESSURE 2
+typedef struct {
+    int kind;                       /* HMG_TRACER_* */
+    const double* d_prof;           /* matter: uk; pressure: pk; HOD: satellite uk   [nz][nm][nk] */
+    const double* d_cprof;          /* HOD: central uk, or NULL meaning u_c == 1 */
+    const double *d_Nc, *d_Ns, *d_NcNs, *d_NsNsm1, *d_ngal;   /* HOD only */
+    const double* d_bias_override;  /* [nz] replaces b (b1_in/b2_in), or NULL */
+} hmg_tracer;
+int hmg_power(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_tracer* h_a, const hmg_tracer* h_b,
+              const double* d_nzm, const double* d_bh, const double* d_ms, const double* d_wm,
+              const double* d_ks, const double* d_Pzk, double rho_m0, double kstar,
+              double* d_P1h /*[nz][nk] or NULL*/, double* d_P2h /*[nz][nk] or NULL*/);
+
+/* ---- z-slab gather over RCCL/xGMI -------------------------------------------------
+ * One communicator per context.  The 128-byte id comes from hmg_comm_unique_id on rank 0
+ * and is distributed by the caller (file, socket, MPI, ...).                                     */
+#define HMG_COMM_ID_BYTES 128
+int hmg_comm_unique_id(char h_id[HMG_COMM_ID_BYTES]);
+int hmg_comm_init(hmg_ctx* ctx, const char h_id[HMG_COMM_ID_BYTES], int rank, int nranks);
+int hmg_comm_allgather(hmg_ctx* ctx, const double* d_send, double* d_recv, size_t count_per_rank);
+/* n gathers of count_per_rank doubles each, fused into one RCCL group launch. */
+int hmg_comm_allgather_multi(hmg_ctx* ctx, int n, const double* const* h_d_send,
+                             double* const* h_d_recv, size_t count_per_rank);
+int hmg_comm_barrier(hmg_ctx* ctx);     /* blocks */
+int hmg_comm_destroy(hmg_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMGRID_H */

@@ -1,0 +1,169 @@
+"""GPU parity: the HIP path (through the C ABI) vs the reference's golden vectors and the
+CPU oracle, same inputs.  Tolerances are SURVEY §8(d)'s parity gate:
+
+    P(z,k):  |dP| <= 1e-8 |P| + 1e-12 max_k |P(z,.)|        (north_star: fp64, tol 1e-8)
+    u(k):    abs <= 1e-12        sigma2,nzm,bh,Nc,Ns,ngal,bg: rel <= 1e-10
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, merged_params, power_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-10
+UK_ABS = 1e-12
+
+
+def build_gpu(g):
+    import hmvec_amd as hm
+    meta = g["meta"]
+    h = hm.HaloModel(g["zs"], g["ks"], ms=g["ms"], params=dict(meta["params"]),
+                     mass_function=meta["mass_function"], mdef=meta["mdef"], accuracy="low",
+                     engine="analytic")
+    return h
+
+
+def add_all(h, g):
+    meta = g["meta"]
+    zs = g["zs"]
+    h.add_battaglia_profile("electron", family=meta["family"], xmax=meta["xmax"], nxs=meta["nxs"],
+                            param_override=meta["batt_override"])
+    central = "electron" if meta["central"] else None
+    if meta["ngal_mode"]:
+        h.add_hod("g", ngal=g["ngal_target"], corr=meta["corr"], central_profile_name=central)
+    else:
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, corr=meta["corr"], central_profile_name=central)
+    if meta["pres"]:
+        h.add_battaglia_pres_profile("y", nxs=meta["nxs"], xmax=meta["xmax"])
+
+
+@pytest.fixture(scope="module", params=["case_a", "case_b", "case_c"])
+def case(request):
+    g = load_golden(request.param)
+    h = build_gpu(g)
+    add_all(h, g)
+    return g, h
+
+
+def test_inputs_identical(case):
+    g, h = case
+    assert rel_err(h.Pzk, g["in_Pzk"]) < 1e-13
+    assert rel_err(h.sPzk, g["in_sPzk"]) < 1e-13
+
+
+def test_mass_function(case):
+    g, h = case
+    assert rel_err(h.sigma2, g["sigma2"]) < REL
+    assert rel_err(h.nzm, g["nzm"]) < 1e-9      # gradient of ln sigma amplifies sigma2's 1e-10
+    assert rel_err(h.bh, g["bh"]) < REL
+    assert rel_err(h.concentration(), g["cs"]) < 1e-13
+    assert rel_err(h._d_rvir.numpy(), g["rvir"]) < 1e-13
+
+
+def test_nfw_and_mass_conversion(case):
+    g, h = case
+    assert np.max(np.abs(h.uk_profiles["nfw"] - g["uk_nfw"])) < UK_ABS
+    m200c, _ = h._m200c()
+    assert rel_err(m200c.numpy(), g["m200c"]) < 1e-11
+
+
+def test_battaglia_profiles(case):
+    g, h = case
+    assert np.max(np.abs(h.uk_profiles["electron"] - g["uk_electron"])) < UK_ABS
+    if g["meta"]["pres"]:
+        pk, ref = h.pk_profiles["y"], g["pk_y"]
+        tol = 1e-9 * np.abs(ref) + 1e-12 * np.max(np.abs(ref), axis=-1, keepdims=True)
+        assert np.all(np.abs(pk - ref) <= tol)
+
+
+def test_numeric_nfw():
+    g = load_golden("case_a")
+    h = build_gpu(g)
+    nn, xm = g["meta"]["numeric_nfw"]
+    ks, u = h.add_nfw_profile("nfwnum", numeric=True, nxs=nn, xmax=xm)
+    assert np.array_equal(ks, g["ks"])
+    assert np.max(np.abs(np.asarray(u) - g["uk_nfwnum"])) < UK_ABS
+
+
+def test_hod(case):
+    g, h = case
+    hod = h.hods["g"]
+    for k in ("Nc", "Ns", "NsNsm1", "NcNs", "ngal", "bg"):
+        assert np.allclose(hod[k], g["hod_" + k], rtol=1e-9, atol=1e-290), k
+    assert np.allclose(hod["log10mthresh"], g["hod_log10mthresh"], rtol=1e-13)
+    assert hod["satellite_profile"] == "nfw"
+
+
+def test_spectra(case):
+    g, h = case
+    names = ["nfw", "electron", "g"] + (["y"] if g["meta"]["pres"] else [])
+    worst = 0.0
+    for i, a in enumerate(names):
+        for b in names[i:]:
+            ok, w = power_close(h.get_power_1halo(a, b), g[f"P1h_{a}_{b}"])
+            assert ok, ("1h", a, b, w)
+            worst = max(worst, w)
+            ok, w = power_close(h.get_power_2halo(a, b), g[f"P2h_{a}_{b}"])
+            assert ok, ("2h", a, b, w)
+            worst = max(worst, w)
+    ok, _ = power_close(h.get_power_1halo("electron", "nfw"), g["P1h_electron_nfw"])
+    assert ok
+    ok, _ = power_close(h.get_power_2halo("g", "nfw", b1_in=g["b1_in"], b2_in=g["b2_in"]), g["P2h_g_nfw_bin"])
+    assert ok
+    ok, _ = power_close(h.get_power("g", "electron"), g["P_tot_g_electron"])
+    assert ok
+    print("worst |dP|/tol =", worst)
+
+
+def test_fused_equals_separate(case):
+    g, h = case
+    for a, b in (("nfw", "nfw"), ("g", "electron"), ("g", "g")):
+        tot = h.get_power(a, b)
+        sep = h.get_power_1halo(a, b) + h.get_power_2halo(a, b)
+        assert np.array_equal(tot, sep)
+
+
+def test_api_errors(case):
+    g, h = case
+    with pytest.raises(AssertionError):
+        h.add_battaglia_profile("electron")
+    with pytest.raises(AssertionError):
+        h.add_battaglia_profile("nfw", ignore_existing=True)
+    with pytest.raises(ValueError):
+        h.get_power_1halo("nope")
+    with pytest.raises(ValueError):
+        h.add_hod("g2", mthresh=np.ones(g["zs"].size + 1))
+    with pytest.raises(ValueError):
+        h.add_hod("g3", mthresh=10 ** 10.5 + g["zs"] * 0, param_override={"not_a_param": 1})
+    with pytest.raises(AssertionError):
+        h.add_hod("g", mthresh=10 ** 10.5 + g["zs"] * 0)
+
+
+def test_readme_config1_anchor():
+    """Config 1/2 at full size (README grid) against a strided sub-sample of the reference."""
+    import hmvec_amd as hm
+    g = load_golden("readme_c1")
+    zs, ms, ks = g["zs"], g["ms"], g["ks"]
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=5000)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    zi, mi, ki = (slice(None, None, int(g[s])) for s in ("zstride", "mstride", "kstride"))
+    assert rel_err(h.sigma2[zi, mi], g["sigma2"]) < REL
+    assert rel_err(h.bh[zi, mi], g["bh"]) < REL
+    assert np.max(np.abs(h.uk_profiles["nfw"][zi, mi, ki] - g["uk_nfw"])) < UK_ABS
+    assert np.max(np.abs(h.uk_profiles["electron"][zi, mi, ki] - g["uk_electron"])) < UK_ABS
+    assert np.allclose(h.hods["g"]["ngal"], g["hod_ngal"], rtol=1e-9)
+    assert np.allclose(h.hods["g"]["bg"], g["hod_bg"], rtol=1e-9)
+    names = ["nfw", "electron", "g"]
+    for i, a in enumerate(names):
+        for b in names[i:]:
+            ok, w = power_close(h.get_power_1halo(a, b)[:, ki], g[f"P1h_{a}_{b}"])
+            assert ok, ("1h", a, b, w)
+            ok, w = power_close(h.get_power_2halo(a, b)[:, ki], g[f"P2h_{a}_{b}"])
+            assert ok, ("2h", a, b, w)
+    # invariants the reference documents
+    p1 = h.get_power_1halo("nfw")
+    p2 = h.get_power_2halo("nfw")
+    assert np.all(p1[:, ks < 1e-3] < 1e-2 * p2[:, ks < 1e-3])          # 1h damped below kstar
+    assert np.allclose(p2[:, 0] / h.Pzk[:, 0], 1.0, rtol=1e-3)          # 2h -> P_lin as k -> 0

@@ -1,0 +1,93 @@
+"""CPU-only checks of the host layer and of the C-ABI library's symbol table.
+
+No compute calls are made here (there is no GPU in the build container).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+from scipy.integrate import simpson
+
+from conftest import REPO, load_golden, merged_params, rel_err
+from hmvec_amd import _native as nat
+from hmvec_amd.background import AnalyticBackground
+from hmvec_amd.cosmology import Cosmology
+from hmvec_amd.quadrature import gradient_is_uniform, simpson_weights, trapz_weights
+
+
+def test_library_exports_every_declared_symbol():
+    """Every hmg_* function declared in include/hmgrid.h must be exported by libhmgrid.so
+    and bound in the ctypes table (and vice versa)."""
+    header = open(os.path.join(REPO, "include", "hmgrid.h")).read()
+    declared = set(re.findall(r"\b(hmg_[a-z0-9_]+)\s*\(", header))
+    declared -= {"hmg_ctx", "hmg_tracer", "hmg_massfn_params", "hmg_hod_params"}
+    assert os.path.exists(nat.LIB_PATH), "libhmgrid.so not built (run __graft_entry__.build())"
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in hmgrid.h but not exported"
+    bound = set(nat.SIGNATURES) | {"hmg_last_error"}
+    assert declared == bound, (declared - bound, bound - declared)
+    assert nat.load().hmg_abi_version() == nat.ABI_VERSION
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setattr(nat, "LIB_PATH", "/nonexistent/libhmgrid.so")
+    with pytest.raises(ImportError, match="no CPU"):
+        nat.load()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8, 9, 2001, 10000])
+def test_simpson_weights_match_scipy(n):
+    x = np.geomspace(1e-4, 2000.0, n)
+    rng = np.random.default_rng(n)
+    y = rng.random(n) + np.sin(x) ** 2
+    assert abs(np.dot(simpson_weights(x), y) / simpson(y, x=x) - 1) < 5e-15
+
+
+def test_trapz_weights_and_gradient_flag():
+    x = np.geomspace(2e10, 1e17, 57)
+    y = np.cos(np.log(x))
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    assert np.isclose(np.dot(trapz_weights(x), y), trapz(y, x), rtol=1e-14)
+    assert gradient_is_uniform(np.arange(5.0))[0] is True
+    assert gradient_is_uniform(np.log(x))[0] == bool((np.diff(np.log(x)) == np.diff(np.log(x))[0]).all())
+
+
+@pytest.mark.parametrize("case", ["case_a", "case_b", "case_c"])
+def test_host_cosmology_reproduces_reference_inputs(case):
+    """The product's own host cosmology (Eisenstein-Hu P(k), densities, H(z)) must give the
+    arrays the reference computed, because they are the inputs of every kernel."""
+    g = load_golden(case)
+    p = merged_params(g["meta"]["params"])
+    cos = Cosmology(p, accuracy="low", engine="analytic")
+    zs, ks = g["zs"], g["ks"]
+    assert rel_err(cos.P_lin_approx(ks, zs), g["in_Pzk"]) < 1e-13
+    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+    assert rel_err(cos.P_lin_approx(ksig, zs), g["in_sPzk"]) < 1e-13
+    assert rel_err(cos.rho_critical_z(zs), g["in_rho_crit_zs"]) < 1e-14
+    assert rel_err(cos.rho_matter_z(0), g["in_rho_matter_0"]) < 1e-14
+    assert rel_err(cos.h_of_z(zs), g["in_h_of_z_zs"]) < 1e-14
+    assert rel_err(cos.comoving_radial_distance(zs), g["in_chi_zs"]) < 1e-13
+    assert abs(cos.h - float(g["in_h"])) < 1e-15 and abs(cos.omm0 - float(g["in_omm0"])) < 1e-15
+
+
+def test_background_distances_consistent():
+    bg = AnalyticBackground(67.3, 0.02225, 0.1198)
+    z = np.array([0.0, 0.5, 2.0])
+    chi = bg.comoving_radial_distance(z)
+    assert chi[0] == 0.0 and np.all(np.diff(chi) > 0)
+    # finite-difference check of d chi / dz = c/H
+    dz = 1e-4
+    num = (bg.comoving_radial_distance(z[1:] + dz) - bg.comoving_radial_distance(z[1:] - dz)) / (2 * dz)
+    assert np.allclose(num, 1.0 / bg.h_of_z(z[1:]), rtol=1e-7)
+    assert np.allclose(bg.angular_diameter_distance2(0.5, 2.0) * 3.0, chi[2] - chi[1], rtol=1e-12)
+
+
+def test_engine_and_accuracy_errors():
+    with pytest.raises(ValueError):
+        Cosmology(engine="bogus")
+    with pytest.raises(ValueError):
+        Cosmology({"sigma8": 0.8}, accuracy="low", engine="analytic")
