@@ -43,6 +43,8 @@ class Tracer(C.Structure):
 MF_SHETH_TORMEN, MF_TINKER10 = 0, 1
 PROF_BATTAGLIA_GAS, PROF_BATTAGLIA_PRES = 1, 2
 TRACER_MATTER, TRACER_HOD, TRACER_PRESSURE = 0, 1, 2
+KERNEL_POWER, KERNEL_NFW, KERNEL_PROFILE_FFT = 0, 1, 2
+EVENT_SLOTS = 4096
 
 _I, _D, _P, _Z = C.c_int, C.c_double, C.c_void_p, C.c_size_t
 # name -> argtypes (restype is int for all but hmg_last_error); mirrors include/hmgrid.h
@@ -58,6 +60,7 @@ SIGNATURES = {
     "hmg_sync": [_P],
     "hmg_event_record": [_P, _I],
     "hmg_elapsed_ms": [_P, _I, _I, C.POINTER(_D)],
+    "hmg_bracket_next": [_P, _I, _I, _I],
     "hmg_sigma2": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P],
     "hmg_massfn": [_P, _I, _I, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P],
     "hmg_halo_structure": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P],

@@ -68,7 +68,8 @@ struct FftPlan {
 struct hmg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[64] = {};
+    hipEvent_t ev[HMG_EVENT_SLOTS] = {};
+    int bracket[HMG_KERNEL_COUNT][2];  // one-shot event brackets per kernel id, -1 = off
     // grow-only scratch arenas (device)
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
@@ -78,6 +79,7 @@ struct hmg_ctx {
     int comm_rank = 0, comm_size = 1;
     double* d_barrier = nullptr;
     int num_cu = 256;
+    hmg_ctx() { for (auto& b : bracket) b[0] = b[1] = -1; }
 };
 
 static int rocfft_refcount = 0;
@@ -850,16 +852,38 @@ int hmg_sync(hmg_ctx* c) {
     return 0;
 }
 int hmg_event_record(hmg_ctx* c, int slot) {
-    REQUIRE(c && slot >= 0 && slot < 64, "bad event slot");
+    REQUIRE(c && slot >= 0 && slot < HMG_EVENT_SLOTS, "bad event slot");
     HIP_TRY(hipEventRecord(c->ev[slot], c->stream));
     return 0;
 }
 int hmg_elapsed_ms(hmg_ctx* c, int s0, int s1, double* ms) {
-    REQUIRE(c && ms && s0 >= 0 && s0 < 64 && s1 >= 0 && s1 < 64, "bad event slot");
+    REQUIRE(c && ms && s0 >= 0 && s0 < HMG_EVENT_SLOTS && s1 >= 0 && s1 < HMG_EVENT_SLOTS, "bad event slot");
     HIP_TRY(hipEventSynchronize(c->ev[s1]));
     float f = 0.f;
     HIP_TRY(hipEventElapsedTime(&f, c->ev[s0], c->ev[s1]));
     *ms = (double)f;
+    return 0;
+}
+
+int hmg_bracket_next(hmg_ctx* c, int kernel_id, int s0, int s1) {
+    REQUIRE(c && kernel_id >= 0 && kernel_id < HMG_KERNEL_COUNT, "bad kernel id");
+    REQUIRE(s0 >= -1 && s0 < HMG_EVENT_SLOTS && s1 >= -1 && s1 < HMG_EVENT_SLOTS, "bad event slot");
+    c->bracket[kernel_id][0] = s0;
+    c->bracket[kernel_id][1] = s1;
+    return 0;
+}
+
+// RAII-free bracket: record start now, return the stop slot (or -1) and clear the one-shot.
+static int bracket_open(hmg_ctx* c, int kid, int* stop_slot) {
+    *stop_slot = -1;
+    const int s0 = c->bracket[kid][0], s1 = c->bracket[kid][1];
+    c->bracket[kid][0] = c->bracket[kid][1] = -1;
+    if (s0 >= 0) HIP_TRY(hipEventRecord(c->ev[s0], c->stream));
+    *stop_slot = s1;
+    return 0;
+}
+static int bracket_close(hmg_ctx* c, int stop_slot) {
+    if (stop_slot >= 0) HIP_TRY(hipEventRecord(c->ev[stop_slot], c->stream));
     return 0;
 }
 
@@ -915,8 +939,11 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
     const size_t blocks = (size_t)nz * nm * ((nk + 255) / 256);
     REQUIRE(blocks <= 2147483647u, "grid too large");
+    int stop = -1;
+    if (bracket_open(c, HMG_KERNEL_NFW, &stop)) return 1;
     hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, nm, nk, cs, rs, zs, ks, uk);
     HIP_TRY(hipGetLastError());
+    if (bracket_close(c, stop)) return 1;
     return 0;
 }
 
@@ -985,6 +1012,8 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
     REQUIRE(step > 0.0, "step must be positive");
     const bool stage = (size_t)nh * sizeof(double) <= 64 * 1024;
     const size_t lds = stage ? (size_t)nh * sizeof(double) : 0;
+    int stop = -1;
+    if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
     for (int r0 = 0; r0 < rows; r0 += chunk) {
         const int nr = rows - r0 < chunk ? rows - r0 : chunk;
         hipLaunchKernelGGL(integrand_kernel, dim3(nr), dim3(256), 0, c->stream, nxs, r0, xs, amp, xcs,
@@ -1003,7 +1032,7 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
                                (const double2*)fout, kts, mnorm, rss, zs, ks, post, out);
         HIP_TRY(hipGetLastError());
     }
-    return 0;
+    return bracket_close(c, stop);
 }
 
 int hmg_hod(hmg_ctx* c, int nz, int nm, const hmg_hod_params* p, const double* zs, const double* ms,
@@ -1049,9 +1078,11 @@ static int launch_power(hmg_ctx* c, const PowerArgs& A, int nz, int ms_split) {
     const size_t lds = (size_t)ms_split * 3 * V * 64 * sizeof(double);
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)power_kernel<NT, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int stop = -1;
+    if (bracket_open(c, HMG_KERNEL_POWER, &stop)) return 1;
     hipLaunchKernelGGL((power_kernel<NT, V>), grid, dim3(64 * ms_split), lds, c->stream, A);
     HIP_TRY(hipGetLastError());
-    return 0;
+    return bracket_close(c, stop);
 }
 
 int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hmg_tracer* tb,

@@ -1,0 +1,128 @@
+"""z-slab sharding of the hot path across the GPUs of one node.
+
+Every stage of the path is independent along z (the mass axis is the reduction axis and
+must not be split), so rank r owns a contiguous slab of redshifts, builds everything for
+its slab with no communication, and the per-rank (nz_local, nk) spectra are joined with a
+single RCCL all-gather group over xGMI.  Because slabs are contiguous in z and spectra are
+[z][k] row-major, the all-gather lands every slab directly in its final position.
+
+The communicator interface is two methods (``allgather_rows``, ``barrier``): ``RcclComm``
+is the product implementation (RCCL inside libhmgrid); tests drive the same sharding logic
+with a torch.distributed/gloo communicator on CPU.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _native as nat
+
+
+def slab_bounds(nz, world, rank):
+    """Contiguous z-slab [lo, hi) of `rank`; requires nz % world == 0 so that a plain
+    all-gather (equal counts) reassembles the full grid."""
+    if nz % world != 0:
+        raise ValueError(f"nz={nz} must be divisible by the number of ranks ({world})")
+    per = nz // world
+    return rank * per, (rank + 1) * per
+
+
+def exchange_unique_id(ctx, rank, world, tag):
+    """Rank 0 creates the RCCL unique id and publishes it through a file; the other ranks
+    of the node poll for it.  (One node only: SURVEY §8e; the id is 128 opaque bytes.)"""
+    path = os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), f"hmg_rdzv_{tag}")
+    buf = C.create_string_buffer(nat.COMM_ID_BYTES)
+    if rank == 0:
+        nat.check(ctx.lib.hmg_comm_unique_id(buf))
+        tmp = path + f".tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(buf.raw)
+        os.replace(tmp, path)
+        return buf
+    deadline = time.time() + 120.0
+    while time.time() < deadline:
+        try:
+            with open(path, "rb") as f:
+                raw = f.read()
+            if len(raw) == nat.COMM_ID_BYTES:
+                buf.raw = raw
+                return buf
+        except FileNotFoundError:
+            pass
+        time.sleep(0.01)
+    raise TimeoutError(f"no RCCL unique id at {path}")
+
+
+class RcclComm:
+    """RCCL communicator owned by the native context."""
+
+    def __init__(self, ctx, rank, world, tag):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self._path = None
+        if world > 1:
+            uid = exchange_unique_id(ctx, rank, world, tag)
+            ctx.call("hmg_comm_init", uid, rank, world)
+            self._path = os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), f"hmg_rdzv_{tag}")
+
+    def allgather_rows(self, sends, recvs):
+        """sends[i]: DeviceArray (nz_local, nk) -> recvs[i]: DeviceArray (nz, nk); one group launch."""
+        n = len(sends)
+        sp = (C.c_void_p * n)(*[s.ptr for s in sends])
+        rp = (C.c_void_p * n)(*[r.ptr for r in recvs])
+        self.ctx.call("hmg_comm_allgather_multi", n, sp, rp, sends[0].size)
+
+    def allgather_host(self, values):
+        """Small host-side all-gather of a float vector (timings); blocks."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        d_s = self.ctx.upload(v)
+        d_r = self.ctx.empty((self.world, v.size))
+        self.ctx.call("hmg_comm_allgather", d_s.ptr, d_r.ptr, v.size)
+        return d_r.numpy()
+
+    def barrier(self):
+        self.ctx.call("hmg_comm_barrier")
+
+    def close(self):
+        if self.world > 1:
+            self.ctx.call("hmg_comm_destroy")
+            if self.rank == 0 and self._path:
+                try:
+                    os.remove(self._path)
+                except OSError:
+                    pass
+
+
+class ShardedSpectra:
+    """Runs a list of (name, name2) spectra on this rank's z-slab model and gathers the
+    full-z (nz, nk) results on every rank.
+
+    `model` is a HaloModel built on the slab redshifts; `comm` provides allgather_rows.
+    """
+
+    def __init__(self, model, comm, nz_total, pairs):
+        self.model, self.comm, self.pairs = model, comm, list(pairs)
+        ctx = model._ctx()
+        nzl, nk = model.zs.size, model.ks.size
+        if nzl * comm.world != nz_total:
+            raise ValueError("slab size x ranks != nz_total")
+        self.local = [ctx.empty((nzl, nk)) for _ in range(2 * len(self.pairs))]
+        if comm.world > 1:
+            self.full = [ctx.empty((nz_total, nk)) for _ in range(2 * len(self.pairs))]
+        else:
+            self.full = self.local
+
+    def run(self, brackets=None):
+        """Launch all spectra + the gather; asynchronous (no host sync)."""
+        m = self.model
+        for i, (a, b) in enumerate(self.pairs):
+            if brackets is not None:
+                m._ctx().call("hmg_bracket_next", nat.KERNEL_POWER, brackets[i][0], brackets[i][1])
+            m.power_device(a, b, out1=self.local[2 * i], out2=self.local[2 * i + 1])
+        if self.comm.world > 1:
+            self.comm.allgather_rows(self.local, self.full)
+
+    def results(self):
+        """{(a,b): (P1h, P2h)} as numpy (nz_total, nk) arrays; blocks."""
+        return {p: (self.full[2 * i].numpy(), self.full[2 * i + 1].numpy())
+                for i, p in enumerate(self.pairs)}

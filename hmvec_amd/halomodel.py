@@ -20,7 +20,7 @@ import scipy.constants as constants
 from . import _native as nat
 from .cosmology import Cosmology
 from .params import battaglia_defaults, default_params
-from .quadrature import gradient_is_uniform, trapz_weights
+from .quadrature import gradient_is_uniform, simpson_weights, trapz_weights
 
 _trapz = getattr(np, "trapezoid", None) or np.trapz
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -63,6 +63,9 @@ class DeviceDict(MutableMapping):
         del self._dev[name]
         self._host.pop(name, None)
 
+    def __contains__(self, name):      # Mapping's default would call __getitem__ (a D2H copy)
+        return name in self._dev
+
     def __iter__(self):
         return iter(self._dev)
 
@@ -91,6 +94,9 @@ class HodEntry(MutableMapping):
     def __delitem__(self, k):
         self._vals.pop(k, None)
         self.dev.pop(k, None)
+
+    def __contains__(self, k):
+        return k in self._vals or k in self.dev
 
     def __iter__(self):
         seen = list(self.dev) + [k for k in self._vals if k not in self.dev]
@@ -128,6 +134,7 @@ class HaloModel(Cosmology):
         self.mode = mass_function
         self.hods = {}
         self._dcache = {}
+        self._pool = {}
 
         self.uk_profiles = DeviceDict(self._ctx)
         self.pk_profiles = DeviceDict(self._ctx)
@@ -175,9 +182,20 @@ class HaloModel(Cosmology):
 
     # ------------------------------------------------------------------ device plumbing
     def _dev(self, key, builder):
+        """Host array -> device, uploaded once per key (inputs of the path stay resident)."""
         if key not in self._dcache:
             self._dcache[key] = self._ctx().upload(builder())
         return self._dcache[key]
+
+    def _buf(self, key, shape):
+        """Output/workspace buffer allocated once per key, so that re-running a stage is
+        launch-only: no allocation, no free, no host synchronisation."""
+        shape = tuple(int(x) for x in shape)
+        b = self._pool.get(key)
+        if b is None or b.shape != shape:
+            b = self._ctx().empty(shape)
+            self._pool[key] = b
+        return b
 
     @property
     def _nz(self):
@@ -219,9 +237,7 @@ class HaloModel(Cosmology):
     # ------------------------------------------------------------------ mass function
     def get_sigma2(self):
         """hmvec/hmvec.py:121-124 — evaluated by hmg_sigma2."""
-        R = self.R_of_m(self.ms)
-        self.get_sigma2_R(R, self.zs)
-        return self._d_sigma2.numpy()
+        return self.sigma2
 
     def _tinker_z_params(self):
         """Per-z scalars of Tinker+10 f(nu) (hmvec/tinker.py:53-66): z clamp with the
@@ -239,8 +255,15 @@ class HaloModel(Cosmology):
         return np.stack([alpha, beta, phi, eta, gamma], axis=1)
 
     def init_mass_function(self, ms):
-        """sigma2, n(z,m), b(z,m), c(z,m), rvir(z,m) on the device (hmvec/hmvec.py:127-185)."""
-        self.ms = np.asarray(ms, dtype=np.float64)
+        """sigma2, n(z,m), b(z,m), c(z,m), rvir(z,m) on the device (hmvec/hmvec.py:127-185).
+        Inputs are uploaded on the first call; later calls only launch kernels."""
+        ms = np.asarray(ms, dtype=np.float64)
+        if getattr(self, "_ms_key", None) is None or not np.array_equal(ms, self._ms_key):
+            for k in [k for k in self._dcache if k != "zs" and k != "ks" and k != "Pzk"
+                      and not (isinstance(k, tuple) and k[0] == "fftgrid")]:
+                self._dcache.pop(k)
+            self._ms_key = ms.copy()
+        self.ms = ms
         if self.mode not in ("sheth-torman", "tinker"):
             raise NotImplementedError
         if self.mdef not in ("vir", "mean"):
@@ -248,35 +271,45 @@ class HaloModel(Cosmology):
         ctx = self._ctx()
         nz, nm = self._nz, self._nm
         self._h_sigma2 = self._h_nzm = self._h_bh = None
-        self._dcache.pop("ms", None)
-        self._dcache.pop("wm", None)
-        self._dcache.pop("m200c", None)
-        # sigma^2
-        R = self.R_of_m(self.ms)
-        self.get_sigma2_R(R, self.zs)          # sets self._d_sigma2 (and self.sPzk)
-        self._h_sigma2 = None
+        # sigma^2: inputs (P(k) on the sigma2 grid, Simpson weights, Lagrangian radii)
+        if "sig_in" not in self._dcache:
+            kmin, kmax, numks = self.p["sigma2_kmin"], self.p["sigma2_kmax"], self.p["sigma2_numks"]
+            kq = np.geomspace(kmin, kmax, numks)
+            if self.accuracy == "high":
+                self.sPzk = self.P_lin_slow(kq, self.zs, kmax=kmax)
+            elif self.accuracy == "medium":
+                self.sPzk = self.P_lin(kq, self.zs)
+            else:
+                self.sPzk = self.P_lin_approx(kq, self.zs)
+            wq = simpson_weights(kq) * kq ** 2.0 / 2.0 / np.pi ** 2
+            self._dcache["sig_in"] = tuple(ctx.upload(a) for a in (self.sPzk, kq, wq, self.R_of_m(ms)))
+        d_sP, d_kq, d_wq, d_R = self._dcache["sig_in"]
+        self._d_sigma2 = self._buf("sigma2", (nz, nm))
+        ctx.call("hmg_sigma2", nz, nm, d_kq.size, d_sP.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
+                 float(self.p["Wkr_taylor_switch"]), self._d_sigma2.ptr)
         # n(z,m), b(z,m)
-        lnm = np.log(self.ms)
-        uniform, step = gradient_is_uniform(lnm)
-        par = nat.MassFnParams(
-            mode=nat.MF_SHETH_TORMEN if self.mode == "sheth-torman" else nat.MF_TINKER10,
-            deltac=self.p["st_deltac"], st_A=self.p["st_A"], st_a=self.p["st_a"], st_p=self.p["st_p"],
-            rho_m0=float(self.rho_matter_z(0)[0]), lnm_uniform=int(uniform), lnm_step=step)
-        d_lnm = ctx.upload(lnm)
-        d_tz = ctx.upload(self._tinker_z_params()) if self.mode == "tinker" else None
-        self._d_nzm, self._d_bh = ctx.empty((nz, nm)), ctx.empty((nz, nm))
+        if "mf_in" not in self._dcache:
+            lnm = np.log(ms)
+            uniform, step = gradient_is_uniform(lnm)
+            par = nat.MassFnParams(
+                mode=nat.MF_SHETH_TORMEN if self.mode == "sheth-torman" else nat.MF_TINKER10,
+                deltac=self.p["st_deltac"], st_A=self.p["st_A"], st_a=self.p["st_a"], st_p=self.p["st_p"],
+                rho_m0=float(self.rho_matter_z(0)[0]), lnm_uniform=int(uniform), lnm_step=step)
+            d_tz = ctx.upload(self._tinker_z_params()) if self.mode == "tinker" else None
+            delta, rho = self._mdef_delta_rho()
+            self._dcache["mf_in"] = (par, ctx.upload(lnm), d_tz, ctx.upload(delta), ctx.upload(rho))
+        par, d_lnm, d_tz, d_delta, d_rho = self._dcache["mf_in"]
+        self._d_nzm, self._d_bh = self._buf("nzm", (nz, nm)), self._buf("bh", (nz, nm))
         ctx.call("hmg_massfn", nz, nm, C.byref(par), self._d_sigma2.ptr, self._d_ms().ptr, d_lnm.ptr,
                  nat.ptr(d_tz), self._d_nzm.ptr, self._d_bh.ptr)
         # c(z,m), rvir(z,m), rs(z,m)
         sfx = self.mdef
-        delta, rho = self._mdef_delta_rho()
-        d_delta, d_rho = ctx.upload(delta), ctx.upload(rho)
-        self._d_cs, self._d_rvir, self._d_rs = (ctx.empty((nz, nm)) for _ in range(3))
+        self._d_cs, self._d_rvir, self._d_rs = (self._buf(k, (nz, nm)) for k in ("cs", "rvir", "rs"))
         ctx.call("hmg_halo_structure", nz, nm, self._d_ms().ptr, self._d_zs().ptr, d_delta.ptr, d_rho.ptr,
                  float(self.p["duffy_A_" + sfx]), float(self.p["duffy_alpha_" + sfx]),
                  float(self.p["duffy_beta_" + sfx]), float(self.h),
                  self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr)
-        ctx.sync()   # temporaries (d_lnm, d_tz, d_delta, d_rho) may now be released
+        self._m200c_valid = False
 
     def get_fsigmaz(self):
         raise NotImplementedError("fused into hmg_massfn; read .nzm / .bh")
@@ -296,19 +329,19 @@ class HaloModel(Cosmology):
     # ------------------------------------------------------------------ profiles
     def _m200c(self):
         """(m200c, r200c) on the device (hmvec/hmvec.py:216-225)."""
-        if "m200c" not in self._dcache:
-            ctx = self._ctx()
-            nz, nm = self._nz, self._nm
-            rhoc = self.rho_critical_z(self.zs)
-            delta, rho = self._mdef_delta_rho()
-            d1 = ctx.upload(rho * delta if self.mdef == "vir" else rho * 200.0)
-            d_rhoc = self._dev("rhocz", lambda: rhoc)
-            m2, r2 = ctx.empty((nz, nm)), ctx.empty((nz, nm))
+        ctx = self._ctx()
+        nz, nm = self._nz, self._nm
+        m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
+        if not getattr(self, "_m200c_valid", False):
+            def drho1():
+                delta, rho = self._mdef_delta_rho()
+                return rho * delta if self.mdef == "vir" else rho * 200.0
+            d1 = self._dev("drho1", drho1)
+            d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
             ctx.call("hmg_mdelta_convert", nz, nm, self._d_ms().ptr, self._d_cs.ptr, d1.ptr, 200.0,
                      d_rhoc.ptr, m2.ptr, r2.ptr)
-            ctx.sync()
-            self._dcache["m200c"] = (m2, r2)
-        return self._dcache["m200c"]
+            self._m200c_valid = True
+        return m2, r2
 
     def _fft_grids(self, xmax, nxs):
         """x grid and FFT wavenumber grid exactly as hmvec/fft.py:45-50,73 build them."""
@@ -321,11 +354,11 @@ class HaloModel(Cosmology):
             self._dcache[key] = (ctx.upload(xs), ctx.upload(kts), float(step))
         return self._dcache[key]
 
-    def _profile_fft(self, nxs, xmax, rowp, consts, gamma, d_cmax, d_rss, do_mass_norm, d_post=None):
+    def _profile_fft(self, key, nxs, xmax, rowp, consts, gamma, d_cmax, d_rss, do_mass_norm, d_post=None):
         ctx = self._ctx()
         nz, nm, nk = self._nz, self._nm, self._nk
         d_xs, d_kts, step = self._fft_grids(xmax, nxs)
-        out = ctx.empty((nz, nm, nk))
+        out = self._buf(key, (nz, nm, nk))
         amp, xc, alpha, expo = rowp
         ctx.call("hmg_profile_fft", nz, nm, nk, int(nxs), step, d_xs.ptr, d_kts.ptr,
                  nat.ptr(amp), nat.ptr(xc), nat.ptr(alpha), nat.ptr(expo),
@@ -334,11 +367,11 @@ class HaloModel(Cosmology):
                  nat.ptr(d_post), out.ptr)
         return out
 
-    def _battaglia_rowparams(self, kind, fit9, gamma, alpha_const, pref, post_pref):
+    def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref):
         ctx = self._ctx()
         nz, nm = self._nz, self._nm
         m200c, r200c = self._m200c()
-        outs = [ctx.empty((nz, nm)) for _ in range(7)]
+        outs = [self._buf((key, "rowp", i), (nz, nm)) for i in range(7)]
         fit = (C.c_double * 9)(*fit9)
         d_hz = self._dev("hz", lambda: self.h_of_z(self.zs))
         d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
@@ -369,11 +402,11 @@ class HaloModel(Cosmology):
         omb = self.p["ombh2"] / self.h ** 2.0
         gamma = pparams["battaglia_gas_gamma"]
         fit9 = [pparams[a + b] for a in ("rho0_", "alpha_", "beta_") for b in ("A0", "alpham", "alphaz")]
+        key = ("uk", name)
         amp, xc, alpha, expo, cmax, rscale, _post = self._battaglia_rowparams(
-            nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0)
-        out = self._profile_fft(nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
+            key, nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0)
+        out = self._profile_fft(key, nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
                                 cmax, rscale, True)
-        self._ctx().sync()
         self.uk_profiles.set_dev(name, out)
 
     def add_battaglia_pres_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
@@ -405,11 +438,11 @@ class HaloModel(Cosmology):
         sigmaT = constants.physical_constants["Thomson cross section"][0]
         mElect = constants.physical_constants["electron mass"][0] / default_params["mSun"]
         post_pref = 4 * np.pi * (sigmaT / (mElect * constants.c ** 2))
+        key = ("pk", name)
         amp, xc, _alpha, expo, cmax, rscale, post = self._battaglia_rowparams(
-            nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref)
-        out = self._profile_fft(nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
+            key, nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref)
+        out = self._profile_fft(key, nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
                                 cmax, rscale, False, d_post=post)
-        self._ctx().sync()
         self.pk_profiles.set_dev(name, out)
 
     def add_nfw_profile(self, name, numeric=False, nxs=None, xmax=None, ignore_existing=False):
@@ -425,10 +458,10 @@ class HaloModel(Cosmology):
         nz, nm, nk = self._nz, self._nm, self._nk
         if numeric:
             # rho = 1/x/(1+x)^2 is the gamma=-1, alpha=1, expo=2 member of the family
-            out = self._profile_fft(nxs, xmax, (None, None, None, None), (1.0, 1.0, 1.0, 2.0), -1.0,
-                                    self._d_cs, self._d_rs, True)
+            out = self._profile_fft(("uk", name), nxs, xmax, (None, None, None, None), (1.0, 1.0, 1.0, 2.0),
+                                    -1.0, self._d_cs, self._d_rs, True)
         else:
-            out = ctx.empty((nz, nm, nk))
+            out = self._buf(("uk", name), (nz, nm, nk))
             ctx.call("hmg_nfw_analytic", nz, nm, nk, self._d_cs.ptr, self._d_rs.ptr, self._d_zs().ptr,
                      self._d_ks().ptr, out.ptr)
         self.uk_profiles.set_dev(name, out)
@@ -440,20 +473,24 @@ class HaloModel(Cosmology):
                    "hod_bisection_search_warn_iter", "hod_alphasat", "hod_Bsat",
                    "hod_betasat", "hod_Bcut", "hod_betacut", "hod_A_log10mthresh"]
 
-    def _hod_device(self, log10mstar_thresh, pparams, corr):
-        """One hmg_hod launch; returns dict of DeviceArrays."""
+    def _hod_device(self, key, log10mstar_thresh, pparams, corr):
+        """One hmg_hod launch into the buffers of `key`; returns dict of DeviceArrays."""
         ctx = self._ctx()
         nz, nm = self._nz, self._nm
         par = nat.HodParams(pparams["hod_sig_log_mstellar"], pparams["hod_alphasat"], pparams["hod_Bsat"],
                             pparams["hod_betasat"], pparams["hod_Bcut"], pparams["hod_betacut"],
                             {"max": 0, "min": 1}[corr])
-        d_thr = ctx.upload(log10mstar_thresh)
-        out = {k: ctx.empty((nz, nm)) for k in ("Nc", "Ns", "NsNsm1", "NcNs")}
-        out["ngal"], out["bg"] = ctx.empty((nz,)), ctx.empty((nz,))
+        thr = np.ascontiguousarray(log10mstar_thresh, dtype=np.float64)
+        cached = self._dcache.get(("thr", key))
+        if cached is None or not np.array_equal(cached[0], thr):
+            cached = (thr.copy(), ctx.upload(thr))
+            self._dcache[("thr", key)] = cached
+        d_thr = cached[1]
+        out = {k: self._buf((key, k), (nz, nm)) for k in ("Nc", "Ns", "NsNsm1", "NcNs")}
+        out["ngal"], out["bg"] = self._buf((key, "ngal"), (nz,)), self._buf((key, "bg"), (nz,))
         ctx.call("hmg_hod", nz, nm, C.byref(par), self._d_zs().ptr, self._d_ms().ptr, d_thr.ptr,
                  self._d_nzm.ptr, self._d_bh.ptr, self._d_wm().ptr, out["Nc"].ptr, out["Ns"].ptr,
                  out["NsNsm1"].ptr, out["NcNs"].ptr, out["ngal"].ptr, out["bg"].ptr)
-        ctx.sync()
         return out
 
     def add_hod(self, name, mthresh=None, ngal=None, corr="max", satellite_profile_name="nfw",
@@ -489,7 +526,7 @@ class HaloModel(Cosmology):
             raise ValueError("mthresh has to be a vector of size self.zs")
 
         l10 = np.log10(np.asarray(mthresh, dtype=np.float64))
-        dev = self._hod_device(l10, pparams, corr)
+        dev = self._hod_device(("hod", name), l10, pparams, corr)
         self.hods[name] = HodEntry(dev, dict(satellite_profile=satellite_profile_name,
                                              central_profile=central_profile_name,
                                              log10mthresh=np.log10(mthresh[:, None])))
@@ -505,7 +542,7 @@ class HaloModel(Cosmology):
         mtol, i, warned = np.inf, 0, False
         while np.any(np.abs(mtol) > rtol):
             ynow = (lo + hi) / 2.0
-            xnow = self._hod_device(ynow, pparams, "max")["ngal"].numpy()
+            xnow = self._hod_device(("hod", "_bisect"), ynow, pparams, "max")["ngal"].numpy()
             mtol = (xnow - ngal) / ngal
             lo[mtol > 0] = ynow[mtol > 0]          # "decreasing" relation
             hi[mtol <= 0] = ynow[mtol <= 0]

@@ -42,9 +42,18 @@ int hmg_memcpy_h2d(hmg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int hmg_memcpy_d2h(hmg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* blocks */
 int hmg_memcpy_d2d(hmg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int hmg_sync(hmg_ctx* ctx);
-/* HIP-event stopwatch on the context's stream: slots 0..63. */
+/* HIP-event stopwatch on the context's stream: slots 0..HMG_EVENT_SLOTS-1. */
+#define HMG_EVENT_SLOTS 4096
 int hmg_event_record(hmg_ctx* ctx, int slot);
 int hmg_elapsed_ms(hmg_ctx* ctx, int slot_start, int slot_stop, double* h_ms);     /* blocks */
+/* One-shot: bracket the NEXT launch of the named kernel with event records at the two
+ * slots (measurement hook for bench.py's roofline; -1,-1 clears).  For HMG_KERNEL_PROFILE_FFT
+ * the bracket spans the integrand + rocFFT + interpolation launches of one hmg_profile_fft. */
+#define HMG_KERNEL_POWER       0
+#define HMG_KERNEL_NFW         1
+#define HMG_KERNEL_PROFILE_FFT 2
+#define HMG_KERNEL_COUNT       3
+int hmg_bracket_next(hmg_ctx* ctx, int kernel_id, int slot_start, int slot_stop);
 
 /* ---- A2: sigma^2(z, R(m)) ------------------------------------------------------
  * Replaces Cosmology.get_sigma2_R (hmvec/cosmology.py:245-269) + Wkr (:30-38).
