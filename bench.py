@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--nk", type=int, default=4096)
     ap.add_argument("--nxs", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-pair", action="store_true", help="six hmg_power launches instead of one hmg_power_batch")
     ap.add_argument("--cpu-sample-nz", type=int, default=16)
     args = ap.parse_args()
 
@@ -105,7 +106,7 @@ def main():
     lo, hi = slab_bounds(zs.size, world, rank)
     zloc = zs[lo:hi]
     K, W = args.steps, args.warmup
-    if 16 + 2 * len(PAIRS) * K + 8 * K > nat.EVENT_SLOTS:
+    if 16 + 16 * K > nat.EVENT_SLOTS:
         sys.exit("too many steps for the event-slot table")
 
     ctx = nat.Context(local_rank)
@@ -118,20 +119,30 @@ def main():
     h.add_hod("g", mthresh=mthr)
     spec = ShardedSpectra(h, comm, zs.size, PAIRS)
 
-    def step(brackets=None, stage_slots=None):
+    BR = {"power": nat.KERNEL_POWER, "nfw": nat.KERNEL_NFW, "fft": nat.KERNEL_PROFILE_FFT}
+    SLOTS_PER_STEP = 16
+
+    def step(base=None):
+        """One full pass of the hot path.  base = first event slot of this step (timed region
+        only): [0..5] stage marks, [6,7] mass-integral kernel, [8,9] NFW kernel, [10,11] FFT chain."""
         def mark(i):
-            if stage_slots is not None:
-                ctx.record(stage_slots + i)
+            if base is not None:
+                ctx.record(base + i)
+        def bracket(name, i):
+            if base is not None:
+                ctx.call("hmg_bracket_next", BR[name], base + i, base + i + 1)
         mark(0)
         h.init_mass_function(ms)
         mark(1)
+        bracket("nfw", 8)
         h.add_nfw_profile("nfw", ignore_existing=True)
         mark(2)
+        bracket("fft", 10)
         h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=args.nxs, ignore_existing=True)
         mark(3)
         h.add_hod("g", mthresh=mthr, ignore_existing=True)
         mark(4)
-        spec.run(brackets)
+        spec.run((base + 6, base + 7) if base is not None else None, batched=not args.per_pair)
         mark(5)
 
     for _ in range(W):
@@ -141,30 +152,40 @@ def main():
     npair = len(PAIRS)
     t0 = time.perf_counter()
     for s in range(K):
-        base = 16 + s * (2 * npair)
-        stage = 16 + 2 * npair * K + 8 * s
-        step([(base + 2 * i, base + 2 * i + 1) for i in range(npair)], stage)
+        step(16 + s * SLOTS_PER_STEP)
     comm.barrier()
     ctx.sync()
     dt = time.perf_counter() - t0
     dt_all = comm.allgather_host([dt]).reshape(-1) if world > 1 else np.array([dt])
     dt_max = float(dt_all.max())
 
-    # per-launch time of the fused mass-integral kernel, HIP events inside the timed region
+    # HIP-event timings recorded inside the timed region, on the stream the kernels run on
     nzl = zloc.size
-    kern_ms = np.zeros(npair)
     stage_ms = np.zeros(5)
+    kern_ms = {"power": 0.0, "nfw": 0.0, "fft": 0.0}
     for s in range(K):
-        base = 16 + s * (2 * npair)
-        stage = 16 + 2 * npair * K + 8 * s
-        for i in range(npair):
-            kern_ms[i] += ctx.elapsed_ms(base + 2 * i, base + 2 * i + 1)
+        base = 16 + s * SLOTS_PER_STEP
         for j in range(5):
-            stage_ms[j] += ctx.elapsed_ms(stage + j, stage + j + 1)
-    kern_ms /= K
+            stage_ms[j] += ctx.elapsed_ms(base + j, base + j + 1)
+        if not args.per_pair:
+            kern_ms["power"] += ctx.elapsed_ms(base + 6, base + 7)
+        kern_ms["nfw"] += ctx.elapsed_ms(base + 8, base + 9)
+        kern_ms["fft"] += ctx.elapsed_ms(base + 10, base + 11)
     stage_ms /= K
-    alg = np.array([power_alg_bytes(nzl, ms.size, ks.size, d) for d in PAIR_TENSORS], dtype=float)
-    achieved = float(alg.sum() / (kern_ms.sum() * 1e-3) / 1e9)
+    kern_ms = {k: v / K for k, v in kern_ms.items()}
+    B, nm_, nk_, nxs = nzl * ms.size, ms.size, ks.size, args.nxs
+    tens_bytes = 8.0 * B * nk_
+    # algorithmic HBM bytes per launch (DESIGN.md "Roofline accounting")
+    alg = {
+        # two distinct tensors (nfw, electron) read once + 12 (nz,nk) outputs + Pzk + per-(z,m) scalars
+        "power": 2 * tens_bytes + 8.0 * nzl * nk_ * (2 * npair + 1) + 8.0 * B * 8,
+        "nfw": tens_bytes,                                     # one 8 B store per grid point
+        "fft": 2 * 8.0 * B * nxs + 2 * 16.0 * B * (nxs // 2 + 1) + tens_bytes,
+    }
+    if args.per_pair:
+        kern_ms["power"] = stage_ms[4]
+        alg["power"] = float(sum(power_alg_bytes(nzl, nm_, nk_, d) for d in PAIR_TENSORS))
+    gbs = {k: alg[k] / (kern_ms[k] * 1e-3) / 1e9 for k in alg}
 
     if rank == 0:
         pts = npair * zs.size * ms.size * ks.size
@@ -179,10 +200,17 @@ def main():
                                    f"6 auto/cross spectra 1h+2h, full path per step",
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
                        "grid_points_per_step": pts},
-            "roofline": {"kernel": "hmg::power_kernel (fused 1h+2h mass integrals, 6 launches/step)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "alg_bytes_per_launch": alg.tolist(), "ms_per_launch": kern_ms.tolist()},
+            "roofline": {"kernel": "hmg::power_batch_kernel (fused 1h+2h mass integrals of all 6 spectra, 1 launch/step)"
+                                   if not args.per_pair else "hmg::power_kernel x6 (per-pair path)",
+                         "bound": "hbm", "achieved": gbs["power"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs["power"] / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"]},
+            "kernels": {
+                "nfw_kernel": {"bound": "fp64-valu", "ms": kern_ms["nfw"], "alg_GBps": gbs["nfw"],
+                               "note": "2 Si/Ci rational evaluations + 2 sincos per 8 B written"},
+                "profile_fft_chain": {"bound": "hbm/infinity-cache", "ms": kern_ms["fft"], "alg_GBps": gbs["fft"],
+                                      "note": "integrand + rocFFT R2C + fused interpolation, chunked to stay in the 256 MiB Infinity Cache"},
+            },
             "stages_ms": dict(zip(["mass_function", "nfw", "battaglia_fft", "hod", "spectra+gather"],
                                   stage_ms.tolist())),
         }

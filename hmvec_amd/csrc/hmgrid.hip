@@ -78,6 +78,7 @@ struct hmg_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     double* d_barrier = nullptr;
+    hmg::SiciTable* d_sici = nullptr;  // Si/Ci coefficients, read through the scalar cache
     int num_cu = 256;
     hmg_ctx() { for (auto& b : bracket) b[0] = b[1] = -1; }
 };
@@ -128,11 +129,12 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubl
 }
 
 // ---------------------------------------------------------------- K1: sigma^2(z,m) (A2)
-// grid (nm, ceil(nz/ZT)); block 256.  The window depends on (m, k') only, so it is
-// evaluated once per block and reused for ZT redshifts held in registers; nothing of
-// shape (nz,nm,nq) is ever materialised (the reference builds 1.3 GB temporaries).
-constexpr int SIG_ZT = 8;
-__global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
+// grid (nm, ceil(nz/ZT)); block 512.  The window depends on (m, k') only and its sincos is
+// the expensive part, so one block evaluates it once per k' and reuses it for ZT redshifts
+// held in registers (ZT = 32 covers Config 3 in one tile); nothing of shape (nz,nm,nq) is
+// ever materialised (the reference builds 1.3 GB temporaries).
+template <int ZT>
+__global__ __launch_bounds__(512) void sigma2_kernel(int nz, int nm, int nq,
                                                      const double* __restrict__ sP,
                                                      const double* __restrict__ kq,
                                                      const double* __restrict__ wq,
@@ -140,11 +142,11 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
                                                      double* __restrict__ out) {
     __shared__ double lds[16];
     const int m = blockIdx.x;
-    const int z0 = blockIdx.y * SIG_ZT;
+    const int z0 = blockIdx.y * ZT;
     const double r = R[m];
-    double acc[SIG_ZT];
+    double acc[ZT];
 #pragma unroll
-    for (int i = 0; i < SIG_ZT; ++i) acc[i] = 0.0;
+    for (int i = 0; i < ZT; ++i) acc[i] = 0.0;
     for (int j = threadIdx.x; j < nq; j += blockDim.x) {
         const double kR = kq[j] * r;
         double w;
@@ -158,13 +160,13 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
         }
         const double a = wq[j] * (w * w);
 #pragma unroll
-        for (int i = 0; i < SIG_ZT; ++i) {
+        for (int i = 0; i < ZT; ++i) {
             const int z = z0 + i;
             if (z < nz) acc[i] += a * sP[(size_t)z * nq + j];
         }
     }
 #pragma unroll
-    for (int i = 0; i < SIG_ZT; ++i) {
+    for (int i = 0; i < ZT; ++i) {
         const double tot = block_sum(acc[i], lds);
         if (threadIdx.x == 0 && z0 + i < nz) out[(size_t)(z0 + i) * nm + m] = tot;
     }
@@ -291,31 +293,46 @@ __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
 }
 
 // ---------------------------------------------------------------- K3: analytic NFW (A6)
-// One thread per grid point, k fastest -> coalesced 8 B stores.  ALU-bound (two Si/Ci
-// rational evaluations + five trig calls per 8 bytes written).
-__global__ __launch_bounds__(256) void nfw_kernel(int nm, int nk, const double* __restrict__ cs,
+// fp64-VALU bound (two Si/Ci rational evaluations + two sincos per 8 bytes written), so the
+// kernel is organised to minimise instructions, not bytes: one block per (z,m) row so the
+// row constants (c, r_s, 1/m_c: a log and two divisions) are computed once per thread
+// instead of once per point; sin(c x) comes from the angle-difference identity on the two
+// sincos the Si/Ci asymptotics need anyway; k is the fast axis -> coalesced 8 B stores.
+__global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ T, int nm, int nk,
+                                                  const double* __restrict__ cs,
                                                   const double* __restrict__ rss,
                                                   const double* __restrict__ zs,
                                                   const double* __restrict__ ks,
                                                   double* __restrict__ uk) {
-    const int ktiles = (nk + 255) >> 8;
-    const int row = blockIdx.x / ktiles;  // z*nm + m
-    const int k = (blockIdx.x - row * ktiles) * 256 + threadIdx.x;
-    if (k >= nk) return;
+    const int row = blockIdx.x;  // z*nm + m
     const int z = row / nm;
     const double c = cs[row];
     const double rs = rss[row];
-    const double mc = log(1.0 + c) - c / (1.0 + c);
-    const double x = ks[k] * rs * (1.0 + zs[z]);
-    const double xc = (1.0 + c) * x;
-    double s1, c1, s2, c2;
-    sincos(x, &s1, &c1);
-    sincos(xc, &s2, &c2);
-    double si1, ci1, si2, ci2;
-    sici_pos(x, s1, c1, si1, ci1);
-    sici_pos(xc, s2, c2, si2, ci2);
-    const double val = (s1 * (si2 - si1) - sin(c * x) / ((1.0 + c) * x) + c1 * (ci2 - ci1)) / mc;
-    uk[(size_t)row * nk + k] = val;
+    const double z1 = 1.0 + zs[z];
+    const double opc = 1.0 + c;
+    const double inv_mc = 1.0 / (log(opc) - c / opc);
+    const double inv_opc2 = 1.0 / (opc * opc);
+    double* __restrict__ dst = uk + (size_t)row * nk;
+    for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+        const double x = ks[k] * rs * z1;
+        const double xc = opc * x;
+        double s1, c1, s2, c2;
+        if (xc < 1.0e9) {
+            sincos_fast(x, s1, c1);
+            sincos_fast(xc, s2, c2);
+        } else {  // outside the Cody-Waite range: library reduction
+            sincos(x, &s1, &c1);
+            sincos(xc, &s2, &c2);
+        }
+        const double zx = rcp_fast(x * x);   // 1/x^2
+        const double zc = zx * inv_opc2;     // 1/xc^2
+        double si1, ci1, si2, ci2;
+        sici_fast(T, x, s1, c1, zx, si1, ci1);
+        sici_fast(T, xc, s2, c2, zc, si2, ci2);
+        const double scx = s2 * c1 - c2 * s1;  // sin(c x) = sin((1+c)x - x)
+        // sin(cx)/((1+c)x) = scx * xc / xc^2
+        dst[k] = (s1 * (si2 - si1) - scx * (xc * zc) + c1 * (ci2 - ci1)) * inv_mc;
+    }
 }
 
 // ---------------------------------------------------------------- A8/X1: row parameters
@@ -363,7 +380,14 @@ __global__ void rowparams_kernel(int kind, int nz, int nm, const double* __restr
 // One block per (z,m) row of the current chunk.  Writes the R2C input x*rho*theta and
 // reduces mnorm = trapz(theta rho x^2, x) in the same pass.  Samples beyond the
 // truncation radius are exact zeros and skip the pow evaluations (85 % of a Battaglia
-// row at xmax=20).
+// row at xmax=20); the row is written with 16 B stores.  trapz on the x grid: the weight
+// of sample j is (x[j+1]-x[j-1])/2, one-sided at the two ends.
+__device__ __forceinline__ double gnfw_rho(double x, double A, double XC, double AL, double EX,
+                                           double gamma) {
+    const double t = x / XC;
+    return A * pow(t, gamma) * pow(1.0 + pow(t, AL), -EX);
+}
+
 __global__ __launch_bounds__(256) void integrand_kernel(
     int nxs, int row0, const double* __restrict__ xs, const double* __restrict__ amp,
     const double* __restrict__ xcs, const double* __restrict__ alphas,
@@ -379,18 +403,30 @@ __global__ __launch_bounds__(256) void integrand_kernel(
     const double cm = cmax[row];
     double* dst = fin + (size_t)lrow * nxs;
     double acc = 0.0;
-    for (int j = threadIdx.x; j < nxs; j += blockDim.x) {
-        const double x = xs[j];
-        double rho = 0.0;
-        if (!(fabs(x) > cm)) {
-            const double t = x / XC;
-            rho = A * pow(t, gamma) * pow(1.0 + pow(t, AL), -EX);
+    const bool vec = ((nxs & 1) == 0);  // rows stay 16 B aligned when nxs is even
+    const int npair = vec ? nxs / 2 : 0;
+    for (int p = threadIdx.x; p < npair; p += blockDim.x) {
+        const int j = 2 * p;
+        const double2 xv = *reinterpret_cast<const double2*>(xs + j);
+        double r0 = 0.0, r1 = 0.0;
+        if (!(fabs(xv.x) > cm)) r0 = gnfw_rho(xv.x, A, XC, AL, EX, gamma);
+        if (!(fabs(xv.y) > cm)) r1 = gnfw_rho(xv.y, A, XC, AL, EX, gamma);
+        *reinterpret_cast<double2*>(dst + j) = make_double2(xv.x * r0, xv.y * r1);
+        if (do_norm && (r0 != 0.0 || r1 != 0.0)) {
+            const double xl = (j > 0) ? xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? xs[j + 2] : xv.y;
+            acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
         }
-        dst[j] = x * rho;
-        if (do_norm) {
-            // trapezoid weight of sample j on the (uniform but not assumed) x grid
-            const double xl = (j > 0) ? xs[j - 1] : x, xr = (j + 1 < nxs) ? xs[j + 1] : x;
-            acc += 0.5 * (xr - xl) * (rho * (x * x));
+    }
+    if (!vec) {
+        for (int j = threadIdx.x; j < nxs; j += blockDim.x) {
+            const double x = xs[j];
+            double rho = 0.0;
+            if (!(fabs(x) > cm)) rho = gnfw_rho(x, A, XC, AL, EX, gamma);
+            dst[j] = x * rho;
+            if (do_norm) {
+                const double xl = (j > 0) ? xs[j - 1] : x, xr = (j + 1 < nxs) ? xs[j + 1] : x;
+                acc += 0.5 * (xr - xl) * (rho * (x * x));
+            }
         }
     }
     if (do_norm) {
@@ -762,6 +798,204 @@ __global__ __launch_bounds__(1024) void power_kernel(PowerArgs A) {
     }
 }
 
+
+// ---------------------------------------------------------------- K6b: all-pairs mass integrals
+// When several spectra share profile tensors (Config 3: six spectra over TWO tensors, because
+// the galaxy tracer's satellite profile is the NFW tensor), the per-pair kernel re-reads
+// each tensor once per pair (sum d = 8 tensor passes).  This kernel takes NTR tracers over NT
+// distinct tensors and accumulates, in ONE pass over the tensors, the NTR 2-halo integrals
+// I_t and all NTR(NTR+1)/2 1-halo integrals; the 2-halo spectrum of any pair is assembled in
+// the epilogue from (I_a, I_b).  Per-tracer forms: W (2-halo weight and cross 1-halo factor)
+// and (A1, A2), the two factors of the tracer's 1-halo AUTO integrand (= W, W except for an
+// HOD, whose auto term is (2 u_c u_s <NcNs> + <Ns(Ns-1)> u_s^2)/ngal^2).
+constexpr int PB_MAXTR = 4;
+constexpr int PB_MAXPAIR = PB_MAXTR * (PB_MAXTR + 1) / 2;
+
+struct BatchPrep {
+    TracerDev tr[PB_MAXTR];
+    int ntr, nt;
+    double rho_m0;
+};
+
+// coef layout per (z,m): [wn, wnb, {W[1+nt], A1[1+nt], A2[1+nt]} x ntr]; side[z][ntr][2] = {b, C}
+__global__ __launch_bounds__(256) void power_batch_prep_kernel(int nm, BatchPrep Q,
+                                                               const double* __restrict__ nzm,
+                                                               const double* __restrict__ bh,
+                                                               const double* __restrict__ ms,
+                                                               const double* __restrict__ wm,
+                                                               double* __restrict__ coef,
+                                                               double* __restrict__ side) {
+    __shared__ double lds[16];
+    const int z = blockIdx.x;
+    const int nc1 = 1 + Q.nt;
+    const int stride = 2 + Q.ntr * 3 * nc1;
+    double accC[PB_MAXTR], accB[PB_MAXTR];
+    for (int t = 0; t < PB_MAXTR; ++t) accC[t] = accB[t] = 0.0;
+    for (int m = threadIdx.x; m < nm; m += blockDim.x) {
+        const size_t idx = (size_t)z * nm + m;
+        const double mass = ms[m];
+        const double wn = wm[m] * nzm[idx];
+        const double wnb = wn * bh[idx];
+        double* c = coef + idx * (size_t)stride;
+        c[0] = wn;
+        c[1] = wnb;
+        for (int t = 0; t < Q.ntr; ++t) {
+            const TracerDev& T = Q.tr[t];
+            double w[1 + PW_MAXT], a1[1 + PW_MAXT], a2[1 + PW_MAXT], low;
+            tracer_form(T, idx, z, mass, Q.rho_m0, w, low);
+            for (int i = 0; i <= PW_MAXT; ++i) { a1[i] = w[i]; a2[i] = w[i]; }
+            if (T.kind == HMG_TRACER_HOD) {
+                for (int i = 0; i <= PW_MAXT; ++i) a1[i] = a2[i] = 0.0;
+                const double ng = T.ngal[z], ng2 = ng * ng;
+                a1[1 + T.t_prof] = 1.0;
+                const double cc = 2.0 * T.NcNs[idx] / ng2;
+                if (T.t_cprof >= 0) a2[1 + T.t_cprof] += cc; else a2[0] += cc;
+                a2[1 + T.t_prof] += T.NsNsm1[idx] / ng2;
+                accB[t] += wnb * (T.Nc[idx] + T.Ns[idx]);
+            }
+            double* ct = c + 2 + t * 3 * nc1;
+            for (int i = 0; i < nc1; ++i) {
+                ct[i] = w[i];
+                ct[nc1 + i] = a1[i];
+                ct[2 * nc1 + i] = a2[i];
+            }
+            accC[t] += wnb * low;
+        }
+    }
+    for (int t = 0; t < Q.ntr; ++t) {
+        const double C = block_sum(accC[t], lds);
+        const double B = block_sum(accB[t], lds);
+        if (threadIdx.x == 0) {
+            const TracerDev& T = Q.tr[t];
+            double b;
+            if (T.kind == HMG_TRACER_MATTER) b = 1.0;
+            else if (T.kind == HMG_TRACER_PRESSURE) b = 0.0;
+            else b = B / T.ngal[z];
+            side[(z * Q.ntr + t) * 2 + 0] = b;
+            side[(z * Q.ntr + t) * 2 + 1] = C;
+        }
+    }
+}
+
+struct BatchArgs {
+    const double* tens[PW_MAXT];
+    const double* coef;
+    const double* side;
+    const double* ks;
+    const double* Pzk;
+    double* P1h[PB_MAXPAIR];  // canonical pair index of (a<=b): a*NTR - a(a-1)/2 + (b-a)
+    double* P2h[PB_MAXPAIR];
+    double kstar;
+    int nm, nk;
+};
+
+template <int NT, int NTR, int V>
+__global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
+    extern __shared__ double red[];  // [MS][V][64] per accumulator, reused
+    using vec_t = typename VecT<V>::type;
+    constexpr int NC1 = 1 + NT;
+    constexpr int STRIDE = 2 + NTR * 3 * NC1;
+    constexpr int NPAIR = NTR * (NTR + 1) / 2;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int MS = blockDim.x >> 6;
+    const int z = blockIdx.y;
+    const int k0 = (blockIdx.x * 64 + lane) * V;
+    const bool live = k0 < A.nk;
+    double I[NTR][V], P[NPAIR][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) I[t][v] = 0.0;
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) P[p][v] = 0.0;
+    }
+    const size_t zrow = (size_t)z * A.nm;
+#pragma unroll 2
+    for (int m = wv; m < A.nm; m += MS) {
+        const double* __restrict__ c = A.coef + (zrow + m) * (size_t)STRIDE;
+        vec_t t[NT];
+        const size_t off = (zrow + m) * (size_t)A.nk + k0;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (live) t[i] = *reinterpret_cast<const vec_t*>(A.tens[i] + off);
+            else t[i] = vec_t{};
+        }
+        const double wn = c[0], wnb = c[1];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            double W[NTR], A1[NTR], A2[NTR];
+#pragma unroll
+            for (int r = 0; r < NTR; ++r) {
+                const double* cr = c + 2 + r * 3 * NC1;
+                double w = cr[0], a1 = cr[NC1], a2 = cr[2 * NC1];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const double tv = vget<V>(t[i], v);
+                    w += cr[1 + i] * tv;
+                    a1 += cr[NC1 + 1 + i] * tv;
+                    a2 += cr[2 * NC1 + 1 + i] * tv;
+                }
+                W[r] = w; A1[r] = a1; A2[r] = a2;
+                I[r][v] += wnb * w;
+            }
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < NTR; ++a) {
+                P[p][v] += wn * (A1[a] * A2[a]);
+                ++p;
+#pragma unroll
+                for (int b = a + 1; b < NTR; ++b) {
+                    P[p][v] += wn * (W[a] * W[b]);
+                    ++p;
+                }
+            }
+        }
+    }
+    // cross-wave reduction through LDS, one accumulator at a time (keeps LDS at MS*V*512 B)
+    auto reduce = [&](double (&acc)[V]) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < V; ++v) red[(wv * V + v) * 64 + lane] = acc[v];
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                double s = 0.0;
+                for (int w = 0; w < MS; ++w) s += red[(w * V + v) * 64 + lane];
+                acc[v] = s;
+            }
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) reduce(I[t]);
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) reduce(P[p]);
+    if (wv == 0 && live) {
+        double bmc[NTR];
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) bmc[t] = A.side[(z * NTR + t) * 2 + 0] - A.side[(z * NTR + t) * 2 + 1];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int k = k0 + v;
+            const size_t o = (size_t)z * A.nk + k;
+            const double q = A.ks[k] / A.kstar;
+            const double damp = 1.0 - exp(-(q * q));
+            const double plin = A.Pzk ? A.Pzk[o] : 0.0;
+            int p = 0;
+#pragma unroll
+            for (int a = 0; a < NTR; ++a) {
+#pragma unroll
+                for (int b = a; b < NTR; ++b) {
+                    if (A.P1h[p]) A.P1h[p][o] = P[p][v] * damp;
+                    if (A.P2h[p]) A.P2h[p][o] = plin * (I[a][v] + bmc[a]) * (I[b][v] + bmc[b]);
+                    ++p;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace hmg
 
 // ------------------------------------------------------------------------------------------
@@ -791,6 +1025,11 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     if (rocfft_refcount++ == 0) FFT_TRY(rocfft_setup());
+    {
+        const hmg::SiciTable t = hmg::sici_table_host();
+        HIP_TRY(hipMalloc((void**)&c->d_sici, sizeof(t)));
+        HIP_TRY(hipMemcpy(c->d_sici, &t, sizeof(t), hipMemcpyHostToDevice));
+    }
     if (const char* s = getenv("HMG_FFT_CHUNK_MB")) c->fft_chunk_bytes = (size_t)atol(s) << 20;
     *out = c;
     return 0;
@@ -808,6 +1047,7 @@ int hmg_ctx_destroy(hmg_ctx* c) {
     }
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
     if (c->d_barrier) (void)hipFree(c->d_barrier);
+    if (c->d_sici) (void)hipFree(c->d_sici);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     if (--rocfft_refcount == 0) rocfft_cleanup();
@@ -891,10 +1131,15 @@ int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const doubl
                const double* wq, const double* R, double tswitch, double* out) {
     REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
-    dim3 grid(nm, (nz + SIG_ZT - 1) / SIG_ZT);
+    const int zt = nz > 16 ? 32 : (nz > 8 ? 16 : (nz > 4 ? 8 : 4));
+    dim3 grid(nm, (nz + zt - 1) / zt);
     REQUIRE(grid.y <= 65535, "nz too large");
-    hipLaunchKernelGGL(sigma2_kernel, grid, dim3(256), 0, c->stream, nz, nm, nq, sP, kq, wq, R,
-                       tswitch, out);
+#define SIG_LAUNCH(ZT_) hipLaunchKernelGGL(sigma2_kernel<ZT_>, grid, dim3(512), 0, c->stream, nz, nm, nq, sP, kq, wq, R, tswitch, out)
+    if (zt == 32) SIG_LAUNCH(32);
+    else if (zt == 16) SIG_LAUNCH(16);
+    else if (zt == 8) SIG_LAUNCH(8);
+    else SIG_LAUNCH(4);
+#undef SIG_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -937,11 +1182,11 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
                      const double* zs, const double* ks, double* uk) {
     REQUIRE(c && cs && rs && zs && ks && uk, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
-    const size_t blocks = (size_t)nz * nm * ((nk + 255) / 256);
+    const size_t blocks = (size_t)nz * nm;
     REQUIRE(blocks <= 2147483647u, "grid too large");
     int stop = -1;
     if (bracket_open(c, HMG_KERNEL_NFW, &stop)) return 1;
-    hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, nm, nk, cs, rs, zs, ks, uk);
+    hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_sici, nm, nk, cs, rs, zs, ks, uk);
     HIP_TRY(hipGetLastError());
     if (bracket_close(c, stop)) return 1;
     return 0;
@@ -1129,6 +1374,85 @@ int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hm
     }
 #undef PW_CASE
     return fail("hmg_power", "unreachable", __FILE__, __LINE__);
+}
+
+template <int NT, int NTR, int V>
+static int launch_power_batch(hmg_ctx* c, const BatchArgs& A, int nz, int ms_split) {
+    const int per_block = 64 * V;
+    dim3 grid((A.nk + per_block - 1) / per_block, nz);
+    const size_t lds = (size_t)ms_split * V * 64 * sizeof(double);
+    int stop = -1;
+    if (bracket_open(c, HMG_KERNEL_POWER, &stop)) return 1;
+    hipLaunchKernelGGL((power_batch_kernel<NT, NTR, V>), grid, dim3(64 * ms_split), lds, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return bracket_close(c, stop);
+}
+
+int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_tracer* tr, int npairs,
+                    const int* pair_a, const int* pair_b, const double* nzm, const double* bh,
+                    const double* ms, const double* wm, const double* ks, const double* Pzk,
+                    double rho_m0, double kstar, double* const* P1h, double* const* P2h) {
+    REQUIRE(c && tr && pair_a && pair_b && nzm && bh && ms && wm && ks, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
+    REQUIRE(nz <= 65535, "nz too large");
+    REQUIRE(ntr >= 1 && ntr <= PB_MAXTR, "1..4 tracers per batch");
+    REQUIRE(npairs >= 1, "no pairs");
+    std::vector<const double*> tens;
+    BatchPrep Q;
+    for (int t = 0; t < ntr; ++t) {
+        REQUIRE(!tr[t].d_bias_override, "bias overrides are not supported in the batched kernel");
+        if (fill_tracer(&tr[t], tens, &Q.tr[t])) return 1;
+    }
+    Q.ntr = ntr;
+    Q.nt = (int)tens.size();
+    Q.rho_m0 = rho_m0;
+    REQUIRE(Q.nt >= 1 && Q.nt <= PW_MAXT, "more than 4 distinct profile tensors in one batch");
+    BatchArgs A;
+    for (int p = 0; p < PB_MAXPAIR; ++p) A.P1h[p] = A.P2h[p] = nullptr;
+    bool any2 = false;
+    for (int i = 0; i < npairs; ++i) {
+        int a = pair_a[i], b = pair_b[i];
+        REQUIRE(a >= 0 && a < ntr && b >= 0 && b < ntr, "pair index out of range");
+        if (a > b) { int t = a; a = b; b = t; }
+        const int p = a * ntr - a * (a - 1) / 2 + (b - a);
+        REQUIRE((P1h && P1h[i]) || (P2h && P2h[i]), "pair without output");
+        REQUIRE(!A.P1h[p] && !A.P2h[p], "the same unordered pair was requested twice");
+        if (P1h && P1h[i]) A.P1h[p] = P1h[i];
+        if (P2h && P2h[i]) { A.P2h[p] = P2h[i]; any2 = true; }
+    }
+    REQUIRE(!any2 || Pzk, "P2h needs Pzk");
+    const int nc1 = 1 + Q.nt;
+    const int stride = 2 + ntr * 3 * nc1;
+    if (ensure_scratch(c, 3, (size_t)nz * nm * stride * 8 + (size_t)nz * ntr * 2 * 8 + 64)) return 1;
+    double* coef = (double*)c->scratch[3];
+    double* side = coef + (size_t)nz * nm * stride;
+    hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz), dim3(256), 0, c->stream, nm, Q, nzm, bh, ms, wm, coef, side);
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < PW_MAXT; ++i) A.tens[i] = i < Q.nt ? tens[i] : nullptr;
+    A.coef = coef; A.side = side; A.ks = ks; A.Pzk = Pzk; A.kstar = kstar; A.nm = nm; A.nk = nk;
+    bool vec2 = (nk % 2 == 0);
+    for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
+    int ms_split = 8;
+    while (ms_split > 1 && ms_split > nm) ms_split >>= 1;
+#define PB_V(NT_, NTR_) return vec2 ? launch_power_batch<NT_, NTR_, 2>(c, A, nz, ms_split) \
+                                    : launch_power_batch<NT_, NTR_, 1>(c, A, nz, ms_split);
+#define PB_NTR(NT_)                         \
+    switch (ntr) {                          \
+        case 1: PB_V(NT_, 1)                \
+        case 2: PB_V(NT_, 2)                \
+        case 3: PB_V(NT_, 3)                \
+        case 4: PB_V(NT_, 4)                \
+    }                                       \
+    break;
+    switch (Q.nt) {
+        case 1: PB_NTR(1)
+        case 2: PB_NTR(2)
+        case 3: PB_NTR(3)
+        case 4: PB_NTR(4)
+    }
+#undef PB_NTR
+#undef PB_V
+    return fail("hmg_power_batch", "unreachable", __FILE__, __LINE__);
 }
 
 // ---- RCCL ------------------------------------------------------------------------------------

@@ -112,13 +112,17 @@ class ShardedSpectra:
         else:
             self.full = self.local
 
-    def run(self, brackets=None):
-        """Launch all spectra + the gather; asynchronous (no host sync)."""
+    def run(self, bracket=None, batched=True):
+        """Launch all spectra + the gather; asynchronous (no host sync).  `bracket` = (s0, s1)
+        event slots around the mass-integral kernel (batched mode) for bench.py."""
         m = self.model
-        for i, (a, b) in enumerate(self.pairs):
-            if brackets is not None:
-                m._ctx().call("hmg_bracket_next", nat.KERNEL_POWER, brackets[i][0], brackets[i][1])
-            m.power_device(a, b, out1=self.local[2 * i], out2=self.local[2 * i + 1])
+        if batched:
+            if bracket is not None:
+                m._ctx().call("hmg_bracket_next", nat.KERNEL_POWER, bracket[0], bracket[1])
+            m.power_device_batch(self.pairs, self.local[0::2], self.local[1::2])
+        else:
+            for i, (a, b) in enumerate(self.pairs):
+                m.power_device(a, b, out1=self.local[2 * i], out2=self.local[2 * i + 1])
         if self.comm.world > 1:
             self.comm.allgather_rows(self.local, self.full)
 

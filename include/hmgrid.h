@@ -185,6 +185,18 @@ int hmg_power(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_tracer* h_a, const
               const double* d_ks, const double* d_Pzk, double rho_m0, double kstar,
               double* d_P1h /*[nz][nk] or NULL*/, double* d_P2h /*[nz][nk] or NULL*/);
 
+/* Same integrals for SEVERAL spectra in one pass: ntr tracers (<= 4) over their distinct
+ * profile tensors (<= 4), npairs (a,b) index pairs into h_tr.  Each distinct tensor is streamed
+ * from HBM once for the whole batch instead of once per pair.  h_P1h[i] / h_P2h[i] are the
+ * device outputs of pair i (either may be NULL).  The reference's first-name-only rule for
+ * two DIFFERENT HOD (or two different pressure) names (hmvec.py:510-513) is not expressible
+ * here: issue those pairs through hmg_power.  No bias overrides.                              */
+int hmg_power_batch(hmg_ctx* ctx, int nz, int nm, int nk, int ntr, const hmg_tracer* h_tr,
+                    int npairs, const int* h_pair_a, const int* h_pair_b,
+                    const double* d_nzm, const double* d_bh, const double* d_ms, const double* d_wm,
+                    const double* d_ks, const double* d_Pzk, double rho_m0, double kstar,
+                    double* const* h_P1h, double* const* h_P2h);
+
 /* ---- z-slab gather over RCCL/xGMI -------------------------------------------------
  * One communicator per context.  The 128-byte id comes from hmg_comm_unique_id on rank 0
  * and is distributed by the caller (file, socket, MPI, ...).                                     */
