@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/hmgrid.h"
+#include "ldsfft.hpp"
 #include "sici.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -65,6 +66,13 @@ struct FftPlan {
     size_t work_bytes = 0;
 };
 
+struct FusedPlan {
+    hmg::FftPlanDev plan;
+    hmg::cplx* twM = nullptr;
+    double2* twN = nullptr;
+    int maxb = 0, maxp = 0;
+};
+
 struct hmg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -74,7 +82,9 @@ struct hmg_ctx {
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     std::map<std::pair<int, int>, FftPlan> plans;  // (nxs, batch) -> plan
+    std::map<int, struct FusedPlan> fused;          // nxs -> workgroup-FFT tables
     size_t fft_chunk_bytes = 0;                    // 0 = default
+    int use_fused_fft = 1;                         // HMG_FUSED_FFT=0 forces the rocFFT path
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     double* d_barrier = nullptr;
@@ -129,47 +139,62 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubl
 }
 
 // ---------------------------------------------------------------- K1: sigma^2(z,m) (A2)
-// grid (nm, ceil(nz/ZT)); block 512.  The window depends on (m, k') only and its sincos is
-// the expensive part, so one block evaluates it once per k' and reuses it for ZT redshifts
-// held in registers (ZT = 32 covers Config 3 in one tile); nothing of shape (nz,nm,nq) is
-// ever materialised (the reference builds 1.3 GB temporaries).
-template <int ZT>
-__global__ __launch_bounds__(512) void sigma2_kernel(int nz, int nm, int nq,
+// sigma2[z,m] = sum_j wq[j] P[z,j] W(kq[j] R[m])^2 is a small contraction over the 10^4-point
+// k' grid.  Each block owns an MT x ZT register tile of (mass, redshift) outputs: per k' it
+// evaluates MT windows (one sincos each, the expensive part) and loads ZT spectrum values,
+// then does MT*ZT FMAs, so both the sincos and the P(k) loads are amortised; nothing of
+// shape (nz,nm,nq) is ever materialised (the reference builds 1.3 GB temporaries).
+template <int MT, int ZT>
+__global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
                                                      const double* __restrict__ sP,
                                                      const double* __restrict__ kq,
                                                      const double* __restrict__ wq,
                                                      const double* __restrict__ R, double tswitch,
                                                      double* __restrict__ out) {
     __shared__ double lds[16];
-    const int m = blockIdx.x;
-    const int z0 = blockIdx.y * ZT;
-    const double r = R[m];
-    double acc[ZT];
+    const int m0 = blockIdx.x * MT, z0 = blockIdx.y * ZT;
+    double r[MT], acc[MT][ZT];
+    const double* prow[ZT];
 #pragma unroll
-    for (int i = 0; i < ZT; ++i) acc[i] = 0.0;
+    for (int i = 0; i < MT; ++i) r[i] = R[min(m0 + i, nm - 1)];
+#pragma unroll
+    for (int i = 0; i < ZT; ++i) prow[i] = sP + (size_t)min(z0 + i, nz - 1) * nq;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < ZT; ++j) acc[i][j] = 0.0;
     for (int j = threadIdx.x; j < nq; j += blockDim.x) {
-        const double kR = kq[j] * r;
-        double w;
-        if (kR < tswitch) {
-            const double xx = kR * kR;
-            w = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
-        } else {
-            double s, c;
-            sincos(kR, &s, &c);
-            w = 3.0 * (s - kR * c) / (kR * kR * kR);
-        }
-        const double a = wq[j] * (w * w);
+        const double kj = kq[j], wj = wq[j];
+        double a[MT];
 #pragma unroll
-        for (int i = 0; i < ZT; ++i) {
-            const int z = z0 + i;
-            if (z < nz) acc[i] += a * sP[(size_t)z * nq + j];
+        for (int i = 0; i < MT; ++i) {
+            const double kR = kj * r[i];
+            double w;
+            if (kR < tswitch) {
+                const double xx = kR * kR;
+                w = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
+            } else {
+                double s, c;
+                sincos(kR, &s, &c);
+                w = 3.0 * (s - kR * c) / (kR * kR * kR);
+            }
+            a[i] = wj * (w * w);
+        }
+#pragma unroll
+        for (int zi = 0; zi < ZT; ++zi) {
+            const double p = prow[zi][j];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][zi] += a[i] * p;
         }
     }
 #pragma unroll
-    for (int i = 0; i < ZT; ++i) {
-        const double tot = block_sum(acc[i], lds);
-        if (threadIdx.x == 0 && z0 + i < nz) out[(size_t)(z0 + i) * nm + m] = tot;
-    }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int zi = 0; zi < ZT; ++zi) {
+            const double tot = block_sum(acc[i][zi], lds);
+            if (threadIdx.x == 0 && m0 + i < nm && z0 + zi < nz)
+                out[(size_t)(z0 + zi) * nm + (m0 + i)] = tot;
+        }
 }
 
 // ---------------------------------------------------------------- K2: mass function (A3/A4)
@@ -499,6 +524,158 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
             }
         }
         dst[i] = post ? val * pf : val;
+    }
+}
+
+// ---------------------------------------------------------------- K45: fused radial-profile transform
+// One workgroup per (z,m) row does the whole of generic_profile_fft (hmvec/fft.py:56-115)
+// without touching HBM in between: integrand + mass norm -> packed-real FFT in LDS
+// (ldsfft.hpp) -> Im F_j -> u_j -> linear interpolation onto the target k grid.  The only
+// HBM traffic is the (nk) output row plus per-row scalars; the rocFFT path it replaces moves
+// 2*8*nxs + 2*16*(nxs/2+1) bytes per row through the memory system (3.2 GB at Config 3).
+// Used when nxs is even, nxs/2 factors into 5/4/3/2 and fits LDS; otherwise hmg_profile_fft
+// falls back to the chunked rocFFT path.
+struct FusedArgs {
+    FftPlanDev plan;
+    int nxs, nm, nk, do_norm;
+    const double* xs;
+    const cplx* twM;     // exp(-2 pi i t / M), t < M
+    const double2* twN;  // (cos, sin)(2 pi j / nxs), j <= M/2
+    const double* kts;
+    const double *amp, *xc, *alpha, *expo;
+    double amp_c, xc_c, alpha_c, expo_c, gamma, step;
+    const double *cmax, *rss, *zs, *ks, *post;
+    double* out;
+};
+
+// amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two
+// powers of t): ~4x fewer VALU ops than three pow() calls; relative error < 2e-15.
+__device__ __forceinline__ double gnfw_rho_fast(double x, double A, double inv_xc, double AL,
+                                                double EX, double gamma) {
+    const double lt = log(x * inv_xc);
+    const double ta = exp(AL * lt);
+    return A * exp(gamma * lt - EX * log1p(ta));
+}
+
+template <int NT, int R, int MAXB>
+__device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ twM, int M, int Ns) {
+    cplx v[MAXB][R];
+    const int nb = M / R;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int j = threadIdx.x + b * NT;
+        if (j < nb) pass_load<R>(buf, twM, M, Ns, j, v[b]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int j = threadIdx.x + b * NT;
+        if (j < nb) pass_store<R>(buf, Ns, j, v[b]);
+    }
+    __syncthreads();
+}
+
+template <int NT, int MAXB, int MAXP>
+__global__ __launch_bounds__(NT) void profile_fused_kernel(FusedArgs A) {
+    // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
+    // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
+    // scratch and the broadcast mass norm.
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    cplx* buf = reinterpret_cast<cplx*>(smem);
+    const int row = blockIdx.x;
+    const int M = A.plan.M, nxs = A.nxs;
+    double* red = smem + 2 * (size_t)M;
+    double& s_mn = red[16];
+    const double Aamp = A.amp ? A.amp[row] : A.amp_c;
+    const double XC = A.xc ? A.xc[row] : A.xc_c;
+    const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
+    const double EX = A.expo ? A.expo[row] : A.expo_c;
+    const double cm = A.cmax[row];
+    const double inv_xc = 1.0 / XC;
+    // ---- phase A: y_n = x_n rho(x_n) theta(x_n <= cmax) packed as (y_2p, y_2p+1); mass norm
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < M; p += NT) {
+        const int j = 2 * p;
+        const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
+        double r0 = 0.0, r1 = 0.0;
+        if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(xv.x, Aamp, inv_xc, AL, EX, A.gamma);
+        if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(xv.y, Aamp, inv_xc, AL, EX, A.gamma);
+        buf[p] = cplx{xv.x * r0, xv.y * r1};
+        if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
+            const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
+            acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
+        }
+    }
+    {
+        const double tot = block_sum(acc, red);   // contains the barrier that publishes buf
+        if (threadIdx.x == 0) s_mn = A.do_norm ? tot : 1.0;
+    }
+    __syncthreads();
+    // ---- phase B: in-place Stockham FFT of length M
+    int Ns = 1;
+    for (int ps = 0; ps < A.plan.npass; ++ps) {
+        const int R = A.plan.radix[ps];
+        if (R == 5) fused_pass<NT, 5, MAXB>(buf, A.twM, M, Ns);
+        else if (R == 4) fused_pass<NT, 4, MAXB>(buf, A.twM, M, Ns);
+        else if (R == 3) fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns);
+        else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns);
+        Ns *= R;
+    }
+    // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm, j = 1..M, into smem[0..M-1]
+    const double inv_mn = 1.0 / s_mn;
+    const double sc = -A.step * inv_mn;
+    double ua[MAXP], ub[MAXP];
+    const int half = M / 2;
+#pragma unroll
+    for (int b = 0; b < MAXP; ++b) {
+        const int j = 1 + threadIdx.x + b * NT;
+        if (j <= half) {
+            const cplx zj = buf[j], zmj = buf[M - j];
+            const double2 w = A.twN[j];
+            double fa, fb;
+            unpack_imag_pair(zj, zmj, w.x, w.y, fa, fb);
+            ua[b] = fa * sc * rcp_fast(A.kts[j]);
+            ub[b] = fb * sc * rcp_fast(A.kts[M - j]);
+        }
+    }
+    __syncthreads();
+    double* u = smem;
+#pragma unroll
+    for (int b = 0; b < MAXP; ++b) {
+        const int j = 1 + threadIdx.x + b * NT;
+        if (j <= half) {
+            u[j - 1] = ua[b];
+            if (M - j >= 1) u[M - j - 1] = ub[b];
+        }
+    }
+    if (threadIdx.x == 0) u[M - 1] = 0.0;  // Nyquist mode: Im F_M == 0
+    __syncthreads();
+    // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid
+    const int z = row / A.nm;
+    const double isc = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));  // kout_j = kts[j] * isc
+    const double pf = A.post ? A.post[row] : 1.0;
+    const double k_lo = A.kts[1] * isc, k_hi = A.kts[M] * isc;
+    const double inv_dk = 1.0 / k_lo;
+    double* __restrict__ dst = A.out + (size_t)row * A.nk;
+    for (int i = threadIdx.x; i < A.nk; i += NT) {
+        const double k = A.ks[i];
+        double val;
+        if (k < k_lo) {
+            val = u[0];
+        } else if (k > k_hi) {
+            val = 0.0;
+        } else if (k == k_hi) {
+            val = u[M - 1];
+        } else {
+            int j = (int)(k * inv_dk);
+            j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
+            double x0 = A.kts[j] * isc, x1 = A.kts[j + 1] * isc;
+            if (x0 > k && j > 1) { --j; x1 = x0; x0 = A.kts[j] * isc; }
+            else if (x1 <= k && j < M - 1) { ++j; x0 = x1; x1 = A.kts[j + 1] * isc; }
+            const double y0 = u[j - 1], y1 = u[j];
+            val = (x0 == k) ? y0 : fma((y1 - y0) * rcp_fast(x1 - x0), k - x0, y0);
+        }
+        dst[i] = val * pf;
     }
 }
 
@@ -1030,6 +1207,7 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
         HIP_TRY(hipMalloc((void**)&c->d_sici, sizeof(t)));
         HIP_TRY(hipMemcpy(c->d_sici, &t, sizeof(t), hipMemcpyHostToDevice));
     }
+    if (const char* s = getenv("HMG_FUSED_FFT")) c->use_fused_fft = atoi(s);
     if (const char* s = getenv("HMG_FFT_CHUNK_MB")) c->fft_chunk_bytes = (size_t)atol(s) << 20;
     *out = c;
     return 0;
@@ -1044,6 +1222,10 @@ int hmg_ctx_destroy(hmg_ctx* c) {
         if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
         if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
         if (kv.second.work) (void)hipFree(kv.second.work);
+    }
+    for (auto& kv : c->fused) {
+        if (kv.second.twM) (void)hipFree(kv.second.twM);
+        if (kv.second.twN) (void)hipFree(kv.second.twN);
     }
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
     if (c->d_barrier) (void)hipFree(c->d_barrier);
@@ -1131,14 +1313,17 @@ int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const doubl
                const double* wq, const double* R, double tswitch, double* out) {
     REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
-    const int zt = nz > 16 ? 32 : (nz > 8 ? 16 : (nz > 4 ? 8 : 4));
-    dim3 grid(nm, (nz + zt - 1) / zt);
-    REQUIRE(grid.y <= 65535, "nz too large");
-#define SIG_LAUNCH(ZT_) hipLaunchKernelGGL(sigma2_kernel<ZT_>, grid, dim3(512), 0, c->stream, nz, nm, nq, sP, kq, wq, R, tswitch, out)
-    if (zt == 32) SIG_LAUNCH(32);
-    else if (zt == 16) SIG_LAUNCH(16);
-    else if (zt == 8) SIG_LAUNCH(8);
-    else SIG_LAUNCH(4);
+    // 32 outputs per block: wide in z when there are many redshifts, wide in m for thin z-slabs
+#define SIG_LAUNCH(MT_, ZT_)                                                                   \
+    do {                                                                                       \
+        dim3 grid((nm + MT_ - 1) / MT_, (nz + ZT_ - 1) / ZT_);                                 \
+        REQUIRE(grid.y <= 65535, "nz too large");                                             \
+        hipLaunchKernelGGL((sigma2_kernel<MT_, ZT_>), grid, dim3(256), 0, c->stream, nz, nm, nq, sP, \
+                           kq, wq, R, tswitch, out);                                           \
+    } while (0)
+    if (nz > 4) SIG_LAUNCH(4, 8);
+    else if (nz > 2) SIG_LAUNCH(8, 4);
+    else SIG_LAUNCH(16, 2);
 #undef SIG_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1231,6 +1416,60 @@ static int get_plan(hmg_ctx* c, int nxs, int batch, FftPlan** out) {
     return 0;
 }
 
+constexpr int FUSED_NT = 512;
+
+// Workgroup-FFT tables for a given nxs; returns nullptr (no error) when the fused kernel
+// cannot take this length.
+static int get_fused_plan(hmg_ctx* c, int nxs, FusedPlan** out) {
+    *out = nullptr;
+    auto it = c->fused.find(nxs);
+    if (it != c->fused.end()) {
+        if (it->second.twM) *out = &it->second;
+        return 0;
+    }
+    FusedPlan P;
+    const int M = nxs / 2;
+    bool ok = (nxs % 2 == 0) && M >= 4 && fft_make_plan(M, &P.plan) && (size_t)M * 16 <= 96 * 1024;
+    if (ok) {
+        int maxb = 0;
+        for (int i = 0; i < P.plan.npass; ++i) {
+            const int nb = M / P.plan.radix[i];
+            maxb = std::max(maxb, (nb + FUSED_NT - 1) / FUSED_NT);
+        }
+        P.maxb = maxb;
+        P.maxp = (M / 2 + FUSED_NT - 1) / FUSED_NT;
+        ok = maxb <= 4 && P.maxp <= 8;
+    }
+    if (!ok) {
+        c->fused[nxs] = FusedPlan();  // remember the rejection
+        return 0;
+    }
+    std::vector<cplx> twM(M);
+    std::vector<double2> twN(M / 2 + 1);
+    const long double twopi = 6.283185307179586476925286766559L;
+    for (int t = 0; t < M; ++t) twM[t] = cplx{(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
+    for (int j = 0; j <= M / 2; ++j) twN[j] = make_double2((double)cosl(twopi * j / nxs), (double)sinl(twopi * j / nxs));
+    HIP_TRY(hipMalloc((void**)&P.twM, twM.size() * sizeof(cplx)));
+    HIP_TRY(hipMalloc((void**)&P.twN, twN.size() * sizeof(double2)));
+    HIP_TRY(hipMemcpy(P.twM, twM.data(), twM.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.twN, twN.data(), twN.size() * sizeof(double2), hipMemcpyHostToDevice));
+    auto res = c->fused.emplace(nxs, P);
+    *out = &res.first->second;
+    return 0;
+}
+
+template <int MAXB, int MAXP>
+static int launch_fused(hmg_ctx* c, const FusedArgs& A, int rows) {
+    const size_t lds = (size_t)A.plan.M * 16 + 32 * sizeof(double);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)profile_fused_kernel<FUSED_NT, MAXB, MAXP>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((profile_fused_kernel<FUSED_NT, MAXB, MAXP>), dim3(rows), dim3(FUSED_NT), lds,
+                       c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, const double* xs, const double* kts,
                     const double* amp, const double* xcs, const double* alpha, const double* expo,
                     double amp_c, double xc_c, double alpha_c, double expo_c, double gamma,
@@ -1241,7 +1480,29 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
     REQUIRE(nxs >= 4, "nxs too small");
     const int nh = nxs / 2;  // rfft output length is nh+1
     const int rows = nz * nm;
-    // Chunk the batch so integrand + spectrum of a chunk stay inside the 256 MiB Infinity Cache:
+    REQUIRE(step > 0.0, "step must be positive");
+    if (c->use_fused_fft) {
+        FusedPlan* FP = nullptr;
+        if (get_fused_plan(c, nxs, &FP)) return 1;
+        if (FP) {
+            FusedArgs A;
+            A.plan = FP->plan; A.nxs = nxs; A.nm = nm; A.nk = nk; A.do_norm = do_mass_norm;
+            A.xs = xs; A.twM = FP->twM; A.twN = FP->twN; A.kts = kts;
+            A.amp = amp; A.xc = xcs; A.alpha = alpha; A.expo = expo;
+            A.amp_c = amp_c; A.xc_c = xc_c; A.alpha_c = alpha_c; A.expo_c = expo_c; A.gamma = gamma;
+            A.step = step; A.cmax = cmax; A.rss = rss; A.zs = zs; A.ks = ks; A.post = post; A.out = out;
+            int stop = -1;
+            if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
+            int rc;
+            const int mb = FP->maxb, mp = FP->maxp;
+            if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
+            else if (mb <= 2 && mp <= 4) rc = launch_fused<2, 4>(c, A, rows);
+            else rc = launch_fused<4, 8>(c, A, rows);
+            if (rc) return 1;
+            return bracket_close(c, stop);
+        }
+    }
+    // ---- rocFFT path.  Chunk the batch so integrand + spectrum of a chunk stay inside the 256 MiB Infinity Cache:
     // the R2C input written by K4 and the spectrum read by K5 then never round-trip through HBM.
     const size_t per_row = (size_t)nxs * 8 + (size_t)(nh + 1) * 16;
     size_t budget = c->fft_chunk_bytes ? c->fft_chunk_bytes : ((size_t)160 << 20);
@@ -1254,7 +1515,6 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
     double* fin = (double*)c->scratch[0];
     double2* fout = (double2*)c->scratch[1];
     double* mnorm = (double*)c->scratch[2];
-    REQUIRE(step > 0.0, "step must be positive");
     const bool stage = (size_t)nh * sizeof(double) <= 64 * 1024;
     const size_t lds = stage ? (size_t)nh * sizeof(double) : 0;
     int stop = -1;

@@ -1,0 +1,137 @@
+// Workgroup-local mixed-radix FFT used by the fused radial-profile kernel.
+//
+// The reference transforms every (z,m) row with np.fft.rfft (hmvec/fft.py:49) and keeps only
+// the imaginary part.  Here one workgroup owns one row: the N real samples are packed as
+// M = N/2 complex numbers in LDS, transformed in place by an autosort (Stockham) FFT with
+// radix-5/4/3/2 passes, and unpacked to Im F_j on the fly, so the row never leaves the CU.
+//
+// The per-thread pieces are plain functions of (thread index, buffer pointer) so the same
+// code is compiled for the GPU (buffer = LDS, a barrier between the load and store halves
+// of each pass) and for the host, where tests/test_ldsfft_cpu.py runs it thread by thread
+// against numpy.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HMG_HD __host__ __device__ __forceinline__
+#else
+#define HMG_HD inline
+#endif
+
+namespace hmg {
+
+struct alignas(16) cplx {
+    double x, y;
+};
+HMG_HD cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+HMG_HD cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
+HMG_HD cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
+// multiply by -i  (forward-transform rotation)
+HMG_HD cplx cmul_mi(cplx a) { return {a.y, -a.x}; }
+
+constexpr int FFT_MAX_PASSES = 16;
+struct FftPlanDev {
+    int M;       // complex length
+    int npass;
+    int radix[FFT_MAX_PASSES];
+};
+
+// Factor M into radices 5,4,3,2 (largest first).  Returns false if a larger prime remains.
+inline bool fft_make_plan(int M, FftPlanDev* p) {
+    p->M = M;
+    p->npass = 0;
+    int rem = M;
+    const int cand[4] = {5, 4, 3, 2};
+    for (int ci = 0; ci < 4; ++ci) {
+        const int r = cand[ci];
+        while (rem % r == 0 && rem > 1) {
+            if (p->npass >= FFT_MAX_PASSES) return false;
+            p->radix[p->npass++] = r;
+            rem /= r;
+        }
+    }
+    return rem == 1 && M >= 2;
+}
+
+// In-place forward DFTs of size R (sign -).
+template <int R>
+HMG_HD void dft_small(cplx* v);
+
+template <>
+HMG_HD void dft_small<2>(cplx* v) {
+    const cplx a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+template <>
+HMG_HD void dft_small<3>(cplx* v) {
+    const double c = -0.5, s = 0.86602540378443864676;  // cos, sin of 2pi/3
+    const cplx t1 = cadd(v[1], v[2]), t2 = csub(v[1], v[2]);
+    const cplx m = {v[0].x + c * t1.x, v[0].y + c * t1.y};
+    const cplx n = {s * t2.x, s * t2.y};
+    v[0] = cadd(v[0], t1);
+    v[1] = cadd(m, cmul_mi(n));
+    v[2] = csub(m, cmul_mi(n));
+}
+template <>
+HMG_HD void dft_small<4>(cplx* v) {
+    const cplx t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    const cplx t2 = cadd(v[1], v[3]), t3 = cmul_mi(csub(v[1], v[3]));
+    v[0] = cadd(t0, t2);
+    v[1] = cadd(t1, t3);
+    v[2] = csub(t0, t2);
+    v[3] = csub(t1, t3);
+}
+template <>
+HMG_HD void dft_small<5>(cplx* v) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos 2pi/5, 4pi/5
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin 2pi/5, 4pi/5
+    const cplx t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    const cplx t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const cplx m1 = {v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y};
+    const cplx m2 = {v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y};
+    const cplx n1 = cmul_mi(cplx{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y});
+    const cplx n2 = cmul_mi(cplx{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y});
+    v[0] = cadd(v[0], cadd(t1, t2));
+    v[1] = cadd(m1, n1);
+    v[4] = csub(m1, n1);
+    v[2] = cadd(m2, n2);
+    v[3] = csub(m2, n2);
+}
+
+// One Stockham pass of radix R on butterfly j (0 <= j < M/R), sub-transform size Ns so far:
+//   load:  v[t] = buf[j + t*M/R] * W_M^(t * k * M/(Ns*R)),  k = j mod Ns
+//   store: buf[(j div Ns)*Ns*R + k + t*Ns] = DFT_R(v)[t]
+// Every load of a pass must precede every store of that pass (barrier on the GPU).
+template <int R>
+HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int j, cplx* v) {
+    const int k = j % Ns;
+    const int stride = M / R;
+    const int tstep = k * (M / (Ns * R));
+    v[0] = buf[j];
+#pragma unroll
+    for (int t = 1; t < R; ++t) {
+        const cplx a = buf[j + t * stride];
+        v[t] = (k == 0) ? a : cmul(a, twM[t * tstep]);
+    }
+}
+template <int R>
+HMG_HD void pass_store(cplx* buf, int Ns, int j, cplx* v) {
+    dft_small<R>(v);
+    const int k = j % Ns;
+    const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+    for (int t = 0; t < R; ++t) buf[j0 + t * Ns] = v[t];
+}
+
+// Unpack the packed-real transform: Z = FFT_M(y[0::2] + i y[1::2]).  For 1 <= j <= M/2, with
+// (a,b) = Z_j, (c,d) = Z_{M-j} and (co,si) = (cos, sin)(2 pi j / N), N = 2M:
+//   Im F_j = P - Q,  Im F_{M-j} = -P - Q,  P = (b-d)/2,  Q = si (b+d)/2 + co (a-c)/2.
+HMG_HD void unpack_imag_pair(cplx zj, cplx zmj, double co, double si, double& imFj, double& imFmj) {
+    const double P = 0.5 * (zj.y - zmj.y);
+    const double Q = si * (0.5 * (zj.y + zmj.y)) + co * (0.5 * (zj.x - zmj.x));
+    imFj = P - Q;
+    imFmj = -P - Q;
+}
+
+}  // namespace hmg

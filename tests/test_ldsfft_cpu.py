@@ -1,0 +1,45 @@
+"""Host check of the workgroup FFT (hmvec_amd/csrc/ldsfft.hpp) that the fused radial-profile
+kernel runs in LDS: the same per-thread code, sequenced thread by thread on the CPU, must
+reproduce numpy's rfft imaginary part (what hmvec/fft.py:49 consumes)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    out = tmp_path_factory.mktemp("ldsfft") / "libldsfft_host.so"
+    src = os.path.join(REPO, "tests", "cpp", "ldsfft_host.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", str(out)], check=True)
+    lib = ctypes.CDLL(str(out))
+    lib.ldsfft_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.ldsfft_rfft_imag.restype = ctypes.c_int
+    return lib
+
+
+@pytest.mark.parametrize("n,threads", [(5000, 512), (5000, 256), (4, 64), (8, 64), (600, 128), (1000, 512),
+                                       (4000, 512), (2 * 3 * 5 * 7 * 2, 64), (12, 64), (20000, 512), (64, 64)])
+def test_matches_numpy_rfft(lib, n, threads):
+    rng = np.random.default_rng(n)
+    y = rng.standard_normal(n) * np.exp(-np.linspace(0, 6, n))
+    out = np.zeros(n // 2 + 1)
+    rc = lib.ldsfft_rfft_imag(y.ctypes.data, n, threads, out.ctypes.data)
+    has_big_prime = any(n // 2 % p == 0 for p in (7, 11, 13))
+    if has_big_prime:
+        assert rc == 2          # unsupported factor -> caller falls back to rocFFT
+        return
+    assert rc == 0
+    ref = np.fft.rfft(y).imag
+    scale = np.max(np.abs(np.fft.rfft(y)))
+    assert np.max(np.abs(out - ref)) < 4e-15 * scale * max(1.0, np.log2(n))
+
+
+def test_odd_length_rejected(lib):
+    y = np.ones(15)
+    out = np.zeros(8)
+    assert lib.ldsfft_rfft_imag(y.ctypes.data, 15, 64, out.ctypes.data) == 1
