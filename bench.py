@@ -187,6 +187,17 @@ def main():
         alg["power"] = float(sum(power_alg_bytes(nzl, nm_, nk_, d) for d in PAIR_TENSORS))
     gbs = {k: alg[k] / (kern_ms[k] * 1e-3) / 1e9 for k in alg}
 
+    # HBM traffic of the roofline kernel from the committed PMC profile (same config only)
+    traffic = None
+    default_cfg = (args.nz, args.nm, args.nk, args.nxs) == (32, 512, 4096, 5000) and world == 1 and not args.per_pair
+    pmc_path = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
+    if default_cfg and os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)["kernels"]
+        for name, rec in pmc.items():
+            if "power_batch_kernel" in name:
+                traffic = rec["hbm_bytes_per_launch_corrected"]
+
     if rank == 0:
         pts = npair * zs.size * ms.size * ks.size
         out = {
@@ -203,7 +214,9 @@ def main():
             "roofline": {"kernel": "hmg::power_batch_kernel (fused 1h+2h mass integrals of all 6 spectra, 1 launch/step)"
                                    if not args.per_pair else "hmg::power_kernel x6 (per-pair path)",
                          "bound": "hbm", "achieved": gbs["power"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs["power"] / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs["power"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                           "(2*FETCH+WRITE)*1024 bytes per launch)" if traffic else None,
                          "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"]},
             "kernels": {
                 "nfw_kernel": {"bound": "fp64-valu", "ms": kern_ms["nfw"], "alg_GBps": gbs["nfw"],

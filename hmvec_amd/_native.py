@@ -58,6 +58,8 @@ SIGNATURES = {
     "hmg_memcpy_d2h": [_P, _P, _P, _Z],
     "hmg_memcpy_d2d": [_P, _P, _P, _Z],
     "hmg_sync": [_P],
+    "hmg_lane_set": [_P, _I],
+    "hmg_event_wait": [_P, _I],
     "hmg_event_record": [_P, _I],
     "hmg_elapsed_ms": [_P, _I, _I, C.POINTER(_D)],
     "hmg_bracket_next": [_P, _I, _I, _I],
@@ -200,6 +202,14 @@ class Context:
 
     def record(self, slot):
         check(self.lib.hmg_event_record(self.handle, slot))
+
+    def lane(self, i):
+        """Route subsequent launches to lane i (0 = main stream)."""
+        check(self.lib.hmg_lane_set(self.handle, i))
+
+    def wait(self, slot):
+        """Current lane waits for the event last recorded in `slot`."""
+        check(self.lib.hmg_event_wait(self.handle, slot))
 
     def elapsed_ms(self, s0, s1):
         ms = C.c_double()

@@ -75,12 +75,14 @@ struct FusedPlan {
 
 struct hmg_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;             // stream of the current lane
+    hipStream_t lanes[HMG_LANES] = {};        // lane 0 is the main stream
+    int lane = 0;
     hipEvent_t ev[HMG_EVENT_SLOTS] = {};
     int bracket[HMG_KERNEL_COUNT][2];  // one-shot event brackets per kernel id, -1 = off
     // grow-only scratch arenas (device)
-    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
     std::map<std::pair<int, int>, FftPlan> plans;  // (nxs, batch) -> plan
     std::map<int, struct FusedPlan> fused;          // nxs -> workgroup-FFT tables
     size_t fft_chunk_bytes = 0;                    // 0 = default
@@ -95,10 +97,15 @@ struct hmg_ctx {
 
 static int rocfft_refcount = 0;
 
+static int sync_all(hmg_ctx* c) {
+    for (auto& st : c->lanes) HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
 static int ensure_scratch(hmg_ctx* c, int slot, size_t bytes) {
     if (c->scratch_bytes[slot] >= bytes) return 0;
     if (c->scratch[slot]) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (sync_all(c)) return 1;
         HIP_TRY(hipFree(c->scratch[slot]));
         c->scratch[slot] = nullptr;
         c->scratch_bytes[slot] = 0;
@@ -153,6 +160,11 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
                                                      double* __restrict__ out) {
     __shared__ double lds[16];
     const int m0 = blockIdx.x * MT, z0 = blockIdx.y * ZT;
+    // blockIdx.z selects a contiguous segment of the k' grid; partial sums go to
+    // out + blockIdx.z * nz * nm and are combined in a fixed order by sigma2_combine_kernel
+    const int seg = (nq + gridDim.z - 1) / gridDim.z;
+    const int j_lo = blockIdx.z * seg, j_hi = min(nq, j_lo + seg);
+    out += (size_t)blockIdx.z * nz * nm;
     double r[MT], acc[MT][ZT];
     const double* prow[ZT];
 #pragma unroll
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < ZT; ++j) acc[i][j] = 0.0;
-    for (int j = threadIdx.x; j < nq; j += blockDim.x) {
+    for (int j = j_lo + threadIdx.x; j < j_hi; j += blockDim.x) {
         const double kj = kq[j], wj = wq[j];
         double a[MT];
 #pragma unroll
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
                 w = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
             } else {
                 double s, c;
-                sincos(kR, &s, &c);
+                if (kR < 1.0e9) sincos_fast(kR, s, c); else sincos(kR, &s, &c);
                 w = 3.0 * (s - kR * c) / (kR * kR * kR);
             }
             a[i] = wj * (w * w);
@@ -195,6 +207,15 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
             if (threadIdx.x == 0 && m0 + i < nm && z0 + zi < nz)
                 out[(size_t)(z0 + zi) * nm + (m0 + i)] = tot;
         }
+}
+
+__global__ void sigma2_combine_kernel(int n, int parts, const double* __restrict__ partial,
+                                      double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < parts; ++p) s += partial[(size_t)p * n + i];
+    out[i] = s;
 }
 
 // ---------------------------------------------------------------- K2: mass function (A3/A4)
@@ -323,13 +344,19 @@ __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
 // row constants (c, r_s, 1/m_c: a log and two divisions) are computed once per thread
 // instead of once per point; sin(c x) comes from the angle-difference identity on the two
 // sincos the Si/Ci asymptotics need anyway; k is the fast axis -> coalesced 8 B stores.
-__global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ T, int nm, int nk,
+// ktile = k values per single-wave workgroup (a multiple of 64)
+__global__ __launch_bounds__(64) void nfw_kernel(const SiciTable* __restrict__ T, int ktile, int nm, int nk,
                                                   const double* __restrict__ cs,
                                                   const double* __restrict__ rss,
                                                   const double* __restrict__ zs,
                                                   const double* __restrict__ ks,
                                                   double* __restrict__ uk) {
-    const int row = blockIdx.x;  // z*nm + m
+    // one wavefront per workgroup: rows x k-tiles of work items keep all SIMDs busy even for a
+    // thin z-slab, and the grid quantises finely (the row constants cost ~1 % per tile)
+    const int ktiles = (nk + ktile - 1) / ktile;
+    const int row = blockIdx.x / ktiles;  // z*nm + m
+    const int k_lo = (blockIdx.x - row * ktiles) * ktile;
+    const int k_hi = min(nk, k_lo + ktile);
     const int z = row / nm;
     const double c = cs[row];
     const double rs = rss[row];
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
     const double inv_mc = 1.0 / (log(opc) - c / opc);
     const double inv_opc2 = 1.0 / (opc * opc);
     double* __restrict__ dst = uk + (size_t)row * nk;
-    for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+    for (int k = k_lo + threadIdx.x; k < k_hi; k += 64) {
         const double x = ks[k] * rs * z1;
         const double xc = opc * x;
         double s1, c1, s2, c2;
@@ -706,7 +733,7 @@ struct HodDev {
 };
 
 // One block per z.  The 4000-point inverse-SHMR table lives in LDS (32 KB).
-__global__ __launch_bounds__(256) void hod_kernel(int nm, HodDev P, const double* __restrict__ zs,
+__global__ __launch_bounds__(1024) void hod_kernel(int nm, HodDev P, const double* __restrict__ zs,
                                                   const double* __restrict__ ms,
                                                   const double* __restrict__ lthr,
                                                   const double* __restrict__ nzm,
@@ -994,21 +1021,24 @@ struct BatchPrep {
     double rho_m0;
 };
 
-// coef layout per (z,m): [wn, wnb, {W[1+nt], A1[1+nt], A2[1+nt]} x ntr]; side[z][ntr][2] = {b, C}
-__global__ __launch_bounds__(256) void power_batch_prep_kernel(int nm, BatchPrep Q,
-                                                               const double* __restrict__ nzm,
-                                                               const double* __restrict__ bh,
-                                                               const double* __restrict__ ms,
-                                                               const double* __restrict__ wm,
-                                                               double* __restrict__ coef,
-                                                               double* __restrict__ side) {
-    __shared__ double lds[16];
-    const int z = blockIdx.x;
+// coef layout per (z,m): [wn, wnb, {W[1+nt], A1[1+nt], A2[1+nt]} x ntr].
+// grid (nz, nblk) with 64-thread blocks, one (z,m) per thread; the k->0 consistency sums C_t
+// and HOD bias numerators B_t are written as per-block partials sidep[z][blk][t][2] = {B, C}
+// and summed in block order by the main kernel's epilogue (deterministic).
+__global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep Q,
+                                                              const double* __restrict__ nzm,
+                                                              const double* __restrict__ bh,
+                                                              const double* __restrict__ ms,
+                                                              const double* __restrict__ wm,
+                                                              double* __restrict__ coef,
+                                                              double* __restrict__ sidep) {
+    const int z = blockIdx.x, blk = blockIdx.y, nblk = gridDim.y;
+    const int m = blk * 64 + threadIdx.x;
     const int nc1 = 1 + Q.nt;
     const int stride = 2 + Q.ntr * 3 * nc1;
     double accC[PB_MAXTR], accB[PB_MAXTR];
     for (int t = 0; t < PB_MAXTR; ++t) accC[t] = accB[t] = 0.0;
-    for (int m = threadIdx.x; m < nm; m += blockDim.x) {
+    if (m < nm) {
         const size_t idx = (size_t)z * nm + m;
         const double mass = ms[m];
         const double wn = wm[m] * nzm[idx];
@@ -1028,7 +1058,7 @@ __global__ __launch_bounds__(256) void power_batch_prep_kernel(int nm, BatchPrep
                 const double cc = 2.0 * T.NcNs[idx] / ng2;
                 if (T.t_cprof >= 0) a2[1 + T.t_cprof] += cc; else a2[0] += cc;
                 a2[1 + T.t_prof] += T.NsNsm1[idx] / ng2;
-                accB[t] += wnb * (T.Nc[idx] + T.Ns[idx]);
+                accB[t] = wnb * (T.Nc[idx] + T.Ns[idx]);
             }
             double* ct = c + 2 + t * 3 * nc1;
             for (int i = 0; i < nc1; ++i) {
@@ -1036,20 +1066,16 @@ __global__ __launch_bounds__(256) void power_batch_prep_kernel(int nm, BatchPrep
                 ct[nc1 + i] = a1[i];
                 ct[2 * nc1 + i] = a2[i];
             }
-            accC[t] += wnb * low;
+            accC[t] = wnb * low;
         }
     }
     for (int t = 0; t < Q.ntr; ++t) {
-        const double C = block_sum(accC[t], lds);
-        const double B = block_sum(accB[t], lds);
+        const double C = wave_sum(accC[t]);
+        const double B = wave_sum(accB[t]);
         if (threadIdx.x == 0) {
-            const TracerDev& T = Q.tr[t];
-            double b;
-            if (T.kind == HMG_TRACER_MATTER) b = 1.0;
-            else if (T.kind == HMG_TRACER_PRESSURE) b = 0.0;
-            else b = B / T.ngal[z];
-            side[(z * Q.ntr + t) * 2 + 0] = b;
-            side[(z * Q.ntr + t) * 2 + 1] = C;
+            double* sp = sidep + ((size_t)(z * nblk + blk) * Q.ntr + t) * 2;
+            sp[0] = B;
+            sp[1] = C;
         }
     }
 }
@@ -1057,7 +1083,10 @@ __global__ __launch_bounds__(256) void power_batch_prep_kernel(int nm, BatchPrep
 struct BatchArgs {
     const double* tens[PW_MAXT];
     const double* coef;
-    const double* side;
+    const double* sidep;             // [nz][nblk][NTR][2] partial {B, C}
+    const double* ngal[PB_MAXTR];    // HOD tracers: ngal[z] (bias = B/ngal); else nullptr
+    double bias_const[PB_MAXTR];     // matter 1, pressure 0
+    int nblk;
     const double* ks;
     const double* Pzk;
     double* P1h[PB_MAXPAIR];  // canonical pair index of (a<=b): a*NTR - a(a-1)/2 + (b-a)
@@ -1149,9 +1178,18 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) reduce(P[p]);
     if (wv == 0 && live) {
-        double bmc[NTR];
+        double bmc[NTR];  // b_t - C_t
 #pragma unroll
-        for (int t = 0; t < NTR; ++t) bmc[t] = A.side[(z * NTR + t) * 2 + 0] - A.side[(z * NTR + t) * 2 + 1];
+        for (int t = 0; t < NTR; ++t) {
+            double B = 0.0, C = 0.0;
+            for (int blk = 0; blk < A.nblk; ++blk) {
+                const double* sp = A.sidep + ((size_t)(z * A.nblk + blk) * NTR + t) * 2;
+                B += sp[0];
+                C += sp[1];
+            }
+            const double bias = A.ngal[t] ? B / A.ngal[t][z] : A.bias_const[t];
+            bmc[t] = bias - C;
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             const int k = k0 + v;
@@ -1199,7 +1237,8 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& st : c->lanes) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->stream = c->lanes[0];
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     if (rocfft_refcount++ == 0) FFT_TRY(rocfft_setup());
     {
@@ -1216,7 +1255,7 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
 int hmg_ctx_destroy(hmg_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    for (auto& st : c->lanes) (void)hipStreamSynchronize(st);
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     for (auto& kv : c->plans) {
         if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
@@ -1231,7 +1270,7 @@ int hmg_ctx_destroy(hmg_ctx* c) {
     if (c->d_barrier) (void)hipFree(c->d_barrier);
     if (c->d_sici) (void)hipFree(c->d_sici);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(c->stream);
+    for (auto& st : c->lanes) (void)hipStreamDestroy(st);
     if (--rocfft_refcount == 0) rocfft_cleanup();
     delete c;
     return 0;
@@ -1246,7 +1285,7 @@ int hmg_malloc(hmg_ctx* c, size_t bytes, void** d_out) {
 int hmg_free(hmg_ctx* c, void* p) {
     REQUIRE(c, "NULL ctx");
     if (!p) return 0;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (sync_all(c)) return 1;
     HIP_TRY(hipFree(p));
     return 0;
 }
@@ -1259,6 +1298,7 @@ int hmg_memcpy_h2d(hmg_ctx* c, void* d, const void* h, size_t bytes) {
 }
 int hmg_memcpy_d2h(hmg_ctx* c, void* h, const void* d, size_t bytes) {
     REQUIRE(c && d && h, "NULL argument");
+    if (sync_all(c)) return 1;  // the producer may have run on any lane
     HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -1270,7 +1310,17 @@ int hmg_memcpy_d2d(hmg_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 int hmg_sync(hmg_ctx* c) {
     REQUIRE(c, "NULL ctx");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    return sync_all(c);
+}
+int hmg_lane_set(hmg_ctx* c, int lane) {
+    REQUIRE(c && lane >= 0 && lane < HMG_LANES, "bad lane");
+    c->lane = lane;
+    c->stream = c->lanes[lane];
+    return 0;
+}
+int hmg_event_wait(hmg_ctx* c, int slot) {
+    REQUIRE(c && slot >= 0 && slot < HMG_EVENT_SLOTS, "bad event slot");
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev[slot], 0));
     return 0;
 }
 int hmg_event_record(hmg_ctx* c, int slot) {
@@ -1313,18 +1363,34 @@ int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const doubl
                const double* wq, const double* R, double tswitch, double* out) {
     REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
-    // 32 outputs per block: wide in z when there are many redshifts, wide in m for thin z-slabs
+    // Tile so that the launch fills the chip: big (mass x redshift) register tiles when the
+    // grid is large, small tiles plus a split of the k' axis for thin z-slabs (multi-GPU).
+    int mt, zt;
+    if (nz > 4) { mt = 2; zt = 8; } else if (nz > 2) { mt = 2; zt = 4; } else { mt = 4; zt = 2; }
+    const long blocks = (long)((nm + mt - 1) / mt) * ((nz + zt - 1) / zt);
+    int ksplit = 1;
+    while (ksplit < 8 && blocks * ksplit < 1024 && nq / (ksplit * 2) >= 256) ksplit *= 2;
+    double* dst = out;
+    if (ksplit > 1) {
+        if (ensure_scratch(c, 4, (size_t)ksplit * nz * nm * 8)) return 1;
+        dst = (double*)c->scratch[4];
+    }
 #define SIG_LAUNCH(MT_, ZT_)                                                                   \
     do {                                                                                       \
-        dim3 grid((nm + MT_ - 1) / MT_, (nz + ZT_ - 1) / ZT_);                                 \
+        dim3 grid((nm + MT_ - 1) / MT_, (nz + ZT_ - 1) / ZT_, ksplit);                         \
         REQUIRE(grid.y <= 65535, "nz too large");                                             \
         hipLaunchKernelGGL((sigma2_kernel<MT_, ZT_>), grid, dim3(256), 0, c->stream, nz, nm, nq, sP, \
-                           kq, wq, R, tswitch, out);                                           \
+                           kq, wq, R, tswitch, dst);                                           \
     } while (0)
-    if (nz > 4) SIG_LAUNCH(4, 8);
-    else if (nz > 2) SIG_LAUNCH(8, 4);
-    else SIG_LAUNCH(16, 2);
+    if (zt == 8) SIG_LAUNCH(2, 8);
+    else if (zt == 4) SIG_LAUNCH(2, 4);
+    else SIG_LAUNCH(4, 2);
 #undef SIG_LAUNCH
+    if (ksplit > 1) {
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sigma2_combine_kernel, grid1d((size_t)nz * nm, 256), dim3(256), 0, c->stream,
+                           nz * nm, ksplit, (const double*)dst, out);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1367,11 +1433,15 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
                      const double* zs, const double* ks, double* uk) {
     REQUIRE(c && cs && rs && zs && ks && uk, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
-    const size_t blocks = (size_t)nz * nm;
+    // 16 k per lane amortises the row constants best; shrink the tile for thin z-slabs so the
+    // grid still covers the chip several times over (~28 resident waves per CU)
+    int ktile = 1024;
+    while (ktile > 256 && (size_t)nz * nm * ((nk + ktile - 1) / ktile) < (size_t)c->num_cu * 28 * 4) ktile >>= 1;
+    const size_t blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
     REQUIRE(blocks <= 2147483647u, "grid too large");
     int stop = -1;
     if (bracket_open(c, HMG_KERNEL_NFW, &stop)) return 1;
-    hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_sici, nm, nk, cs, rs, zs, ks, uk);
+    hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(64), 0, c->stream, c->d_sici, ktile, nm, nk, cs, rs, zs, ks, uk);
     HIP_TRY(hipGetLastError());
     if (bracket_close(c, stop)) return 1;
     return 0;
@@ -1528,6 +1598,7 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
         if (get_plan(c, nxs, nr, &P)) return 1;
         void* ib[1] = {fin};
         void* ob[1] = {fout};
+        FFT_TRY(rocfft_execution_info_set_stream(P->info, c->stream));
         FFT_TRY(rocfft_execute(P->plan, ib, ob, P->info));
         if (stage)
             hipLaunchKernelGGL(interp_kernel<true>, dim3(nr), dim3(256), lds, c->stream, nm, nk, nh, r0, step,
@@ -1548,7 +1619,7 @@ int hmg_hod(hmg_ctx* c, int nz, int nm, const hmg_hod_params* p, const double* z
     REQUIRE(nz > 0 && nm > 0, "empty grid");
     REQUIRE(p->corr == 0 || p->corr == 1, "corr must be 0 (max) or 1 (min)");
     HodDev P{p->sig_log_mstellar, p->alphasat, p->Bsat, p->betasat, p->Bcut, p->betacut, p->corr};
-    hipLaunchKernelGGL(hod_kernel, dim3(nz), dim3(256), 0, c->stream, nm, P, zs, ms, lthr, nzm, bh, wm,
+    hipLaunchKernelGGL(hod_kernel, dim3(nz), dim3(1024), 0, c->stream, nm, P, zs, ms, lthr, nzm, bh, wm,
                        Nc, Ns, NsNsm1, NcNs, ngal, bg);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1683,15 +1754,24 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     REQUIRE(!any2 || Pzk, "P2h needs Pzk");
     const int nc1 = 1 + Q.nt;
     const int stride = 2 + ntr * 3 * nc1;
-    if (ensure_scratch(c, 3, (size_t)nz * nm * stride * 8 + (size_t)nz * ntr * 2 * 8 + 64)) return 1;
+    const int nblk = (nm + 63) / 64;
+    REQUIRE(nblk <= 65535, "nm too large");
+    if (ensure_scratch(c, 3, (size_t)nz * nm * stride * 8 + (size_t)nz * nblk * ntr * 2 * 8 + 64)) return 1;
     double* coef = (double*)c->scratch[3];
-    double* side = coef + (size_t)nz * nm * stride;
-    hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz), dim3(256), 0, c->stream, nm, Q, nzm, bh, ms, wm, coef, side);
+    double* sidep = coef + (size_t)nz * nm * stride;
+    hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, nblk), dim3(64), 0, c->stream, nm, Q, nzm, bh, ms, wm, coef, sidep);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < PW_MAXT; ++i) A.tens[i] = i < Q.nt ? tens[i] : nullptr;
-    A.coef = coef; A.side = side; A.ks = ks; A.Pzk = Pzk; A.kstar = kstar; A.nm = nm; A.nk = nk;
+    for (int t = 0; t < PB_MAXTR; ++t) {
+        A.ngal[t] = (t < ntr && tr[t].kind == HMG_TRACER_HOD) ? tr[t].d_ngal : nullptr;
+        A.bias_const[t] = (t < ntr && tr[t].kind == HMG_TRACER_MATTER) ? 1.0 : 0.0;
+    }
+    A.nblk = nblk;
+    A.coef = coef; A.sidep = sidep; A.ks = ks; A.Pzk = Pzk; A.kstar = kstar; A.nm = nm; A.nk = nk;
     bool vec2 = (nk % 2 == 0);
     for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
+    // thin z-slabs: narrower k tiles so that every CU still gets a workgroup
+    if (vec2 && (long)((nk + 127) / 128) * nz < c->num_cu) vec2 = false;
     int ms_split = 8;
     while (ms_split > 1 && ms_split > nm) ms_split >>= 1;
 #define PB_V(NT_, NTR_) return vec2 ? launch_power_batch<NT_, NTR_, 2>(c, A, nz, ms_split) \
@@ -1770,6 +1850,7 @@ int hmg_comm_allgather_multi(hmg_ctx* c, int n, const double* const* send, doubl
 }
 int hmg_comm_barrier(hmg_ctx* c) {
     REQUIRE(c, "NULL ctx");
+    if (sync_all(c)) return 1;
     if (c->comm) NCCL_TRY(ncclAllReduce(c->d_barrier, c->d_barrier, 1, ncclDouble, ncclSum, c->comm, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;

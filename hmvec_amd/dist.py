@@ -28,10 +28,18 @@ def slab_bounds(nz, world, rank):
     return rank * per, (rank + 1) * per
 
 
+def rendezvous_path(tag, world):
+    """One file per launch: the tag (MASTER_PORT + run id from the launcher), the world size
+    and the launcher's PID, which all ranks of one torch.distributed.run share as parent."""
+    name = f"hmg_rdzv_{tag}_w{world}_pp{os.getppid()}"
+    return os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), name)
+
+
 def exchange_unique_id(ctx, rank, world, tag):
     """Rank 0 creates the RCCL unique id and publishes it through a file; the other ranks
-    of the node poll for it.  (One node only: SURVEY §8e; the id is 128 opaque bytes.)"""
-    path = os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), f"hmg_rdzv_{tag}")
+    of the node poll for it.  (One node only: SURVEY §8e; the id is 128 opaque bytes.)
+    Files older than 10 minutes are ignored as leftovers of a crashed launch."""
+    path = rendezvous_path(tag, world)
     buf = C.create_string_buffer(nat.COMM_ID_BYTES)
     if rank == 0:
         nat.check(ctx.lib.hmg_comm_unique_id(buf))
@@ -43,9 +51,10 @@ def exchange_unique_id(ctx, rank, world, tag):
     deadline = time.time() + 120.0
     while time.time() < deadline:
         try:
+            fresh = time.time() - os.path.getmtime(path) < 600.0
             with open(path, "rb") as f:
                 raw = f.read()
-            if len(raw) == nat.COMM_ID_BYTES:
+            if fresh and len(raw) == nat.COMM_ID_BYTES:
                 buf.raw = raw
                 return buf
         except FileNotFoundError:
@@ -63,7 +72,7 @@ class RcclComm:
         if world > 1:
             uid = exchange_unique_id(ctx, rank, world, tag)
             ctx.call("hmg_comm_init", uid, rank, world)
-            self._path = os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), f"hmg_rdzv_{tag}")
+            self._path = rendezvous_path(tag, world)
 
     def allgather_rows(self, sends, recvs):
         """sends[i]: DeviceArray (nz_local, nk) -> recvs[i]: DeviceArray (nz, nk); one group launch."""

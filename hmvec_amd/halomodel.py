@@ -135,6 +135,8 @@ class HaloModel(Cosmology):
         self.hods = {}
         self._dcache = {}
         self._pool = {}
+        self._use_lanes = os.environ.get("HMG_LANES", "0") == "1"   # multi-stream overlap; off by default
+        self._recorded = set()
 
         self.uk_profiles = DeviceDict(self._ctx)
         self.pk_profiles = DeviceDict(self._ctx)
@@ -186,6 +188,29 @@ class HaloModel(Cosmology):
         if key not in self._dcache:
             self._dcache[key] = self._ctx().upload(builder())
         return self._dcache[key]
+
+    # -- lanes (multi-stream dataflow).  Lane 0: sigma2 -> n(z,m), b(z,m) -> HOD -> spectra.
+    # Lane 1: c, rvir, r_s -> analytic NFW.  Lane 2: mass conversion -> profile rows -> FFT.
+    # Event slots 0..7 are reserved for this class (bench.py uses slots >= 16).
+    _EV_EPOCH, _EV_HALO, _EV_TAIL1, _EV_TAIL2 = 0, 1, 2, 3
+
+    def _on_lane(self, lane, wait_slots=()):
+        ctx = self._ctx()
+        ctx.lane(lane if self._use_lanes else 0)
+        if self._use_lanes:
+            for sl in wait_slots:
+                if sl in self._recorded:
+                    ctx.wait(sl)
+        return ctx
+
+    def _mark(self, slot):
+        if self._use_lanes:
+            self._ctx().record(slot)
+            self._recorded.add(slot)
+
+    def _join_profiles(self):
+        """Lane 0 waits for everything enqueued on the profile lanes."""
+        return self._on_lane(0, (self._EV_TAIL1, self._EV_TAIL2))
 
     def _buf(self, key, shape):
         """Output/workspace buffer allocated once per key, so that re-running a stage is
@@ -284,6 +309,8 @@ class HaloModel(Cosmology):
             wq = simpson_weights(kq) * kq ** 2.0 / 2.0 / np.pi ** 2
             self._dcache["sig_in"] = tuple(ctx.upload(a) for a in (self.sPzk, kq, wq, self.R_of_m(ms)))
         d_sP, d_kq, d_wq, d_R = self._dcache["sig_in"]
+        ctx = self._join_profiles()      # everything launched so far is ordered before this point
+        self._mark(self._EV_EPOCH)
         self._d_sigma2 = self._buf("sigma2", (nz, nm))
         ctx.call("hmg_sigma2", nz, nm, d_kq.size, d_sP.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
                  float(self.p["Wkr_taylor_switch"]), self._d_sigma2.ptr)
@@ -302,13 +329,17 @@ class HaloModel(Cosmology):
         self._d_nzm, self._d_bh = self._buf("nzm", (nz, nm)), self._buf("bh", (nz, nm))
         ctx.call("hmg_massfn", nz, nm, C.byref(par), self._d_sigma2.ptr, self._d_ms().ptr, d_lnm.ptr,
                  nat.ptr(d_tz), self._d_nzm.ptr, self._d_bh.ptr)
-        # c(z,m), rvir(z,m), rs(z,m)
+        # c(z,m), rvir(z,m), rs(z,m): independent of sigma2 -> lane 1
         sfx = self.mdef
         self._d_cs, self._d_rvir, self._d_rs = (self._buf(k, (nz, nm)) for k in ("cs", "rvir", "rs"))
+        ctx = self._on_lane(1, (self._EV_EPOCH,))
         ctx.call("hmg_halo_structure", nz, nm, self._d_ms().ptr, self._d_zs().ptr, d_delta.ptr, d_rho.ptr,
                  float(self.p["duffy_A_" + sfx]), float(self.p["duffy_alpha_" + sfx]),
                  float(self.p["duffy_beta_" + sfx]), float(self.h),
                  self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr)
+        self._mark(self._EV_HALO)
+        self._mark(self._EV_TAIL1)
+        self._on_lane(0)
         self._m200c_valid = False
 
     def get_fsigmaz(self):
@@ -333,6 +364,8 @@ class HaloModel(Cosmology):
         nz, nm = self._nz, self._nm
         m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
         if not getattr(self, "_m200c_valid", False):
+            if self._use_lanes and self._EV_HALO in self._recorded:
+                ctx.wait(self._EV_HALO)       # c(z,m) is produced on lane 1
             def drho1():
                 delta, rho = self._mdef_delta_rho()
                 return rho * delta if self.mdef == "vir" else rho * 200.0
@@ -403,10 +436,13 @@ class HaloModel(Cosmology):
         gamma = pparams["battaglia_gas_gamma"]
         fit9 = [pparams[a + b] for a in ("rho0_", "alpha_", "beta_") for b in ("A0", "alpham", "alphaz")]
         key = ("uk", name)
+        self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
         amp, xc, alpha, expo, cmax, rscale, _post = self._battaglia_rowparams(
             key, nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0)
         out = self._profile_fft(key, nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
                                 cmax, rscale, True)
+        self._mark(self._EV_TAIL2)
+        self._on_lane(0)
         self.uk_profiles.set_dev(name, out)
 
     def add_battaglia_pres_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
@@ -439,10 +475,13 @@ class HaloModel(Cosmology):
         mElect = constants.physical_constants["electron mass"][0] / default_params["mSun"]
         post_pref = 4 * np.pi * (sigmaT / (mElect * constants.c ** 2))
         key = ("pk", name)
+        self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
         amp, xc, _alpha, expo, cmax, rscale, post = self._battaglia_rowparams(
             key, nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref)
         out = self._profile_fft(key, nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
                                 cmax, rscale, False, d_post=post)
+        self._mark(self._EV_TAIL2)
+        self._on_lane(0)
         self.pk_profiles.set_dev(name, out)
 
     def add_nfw_profile(self, name, numeric=False, nxs=None, xmax=None, ignore_existing=False):
@@ -458,12 +497,17 @@ class HaloModel(Cosmology):
         nz, nm, nk = self._nz, self._nm, self._nk
         if numeric:
             # rho = 1/x/(1+x)^2 is the gamma=-1, alpha=1, expo=2 member of the family
+            self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
             out = self._profile_fft(("uk", name), nxs, xmax, (None, None, None, None), (1.0, 1.0, 1.0, 2.0),
                                     -1.0, self._d_cs, self._d_rs, True)
+            self._mark(self._EV_TAIL2)
         else:
             out = self._buf(("uk", name), (nz, nm, nk))
+            ctx = self._on_lane(1, (self._EV_EPOCH,))
             ctx.call("hmg_nfw_analytic", nz, nm, nk, self._d_cs.ptr, self._d_rs.ptr, self._d_zs().ptr,
                      self._d_ks().ptr, out.ptr)
+            self._mark(self._EV_TAIL1)
+        self._on_lane(0)
         self.uk_profiles.set_dev(name, out)
         return self.ks, _LazyArray(self.uk_profiles, name)
 
@@ -580,7 +624,7 @@ class HaloModel(Cosmology):
         raise ValueError
 
     def _power_launch(self, ta, tb, want1, want2, out1=None, out2=None):
-        ctx = self._ctx()
+        ctx = self._join_profiles()
         nz, nm, nk = self._nz, self._nm, self._nk
         d1 = (out1 if out1 is not None else ctx.empty((nz, nk))) if want1 else None
         d2 = (out2 if out2 is not None else ctx.empty((nz, nk))) if want2 else None
@@ -663,6 +707,7 @@ class HaloModel(Cosmology):
             alias.append(uniq.index(key))
         first = [alias.index(u) for u in range(len(uniq))]
         n = len(uniq)
+        ctx = self._join_profiles()
         tr = (nat.Tracer * len(names))(*[r[0] for r in res1])
         pa = (C.c_int * n)(*[u[0] for u in uniq])
         pb = (C.c_int * n)(*[u[1] for u in uniq])

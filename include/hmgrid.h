@@ -41,7 +41,16 @@ int hmg_free(hmg_ctx* ctx, void* d_ptr);
 int hmg_memcpy_h2d(hmg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int hmg_memcpy_d2h(hmg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* blocks */
 int hmg_memcpy_d2d(hmg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
-int hmg_sync(hmg_ctx* ctx);
+int hmg_sync(hmg_ctx* ctx);                      /* waits for every lane */
+/* Lanes: HMG_LANES HIP streams per context.  Every entry point enqueues on the CURRENT lane
+ * (default 0).  Independent stages of the path (e.g. the NFW kernel and the profile-FFT kernel,
+ * or the small per-(z,m) kernels) may be put on different lanes and ordered with events:
+ * hmg_event_record(slot) on the producer lane, hmg_event_wait(slot) on the consumer lane.
+ * hmg_memcpy_d2h, hmg_free and hmg_sync wait for all lanes.  Scratch inside the context is
+ * shared: do not run the SAME entry point concurrently on two lanes.                        */
+#define HMG_LANES 4
+int hmg_lane_set(hmg_ctx* ctx, int lane);
+int hmg_event_wait(hmg_ctx* ctx, int slot);      /* current lane waits for the event last recorded in slot */
 /* HIP-event stopwatch on the context's stream: slots 0..HMG_EVENT_SLOTS-1. */
 #define HMG_EVENT_SLOTS 4096
 int hmg_event_record(hmg_ctx* ctx, int slot);

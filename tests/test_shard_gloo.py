@@ -1,0 +1,49 @@
+"""World-size-2 CPU rehearsal of the multi-GPU path (prompt §5): contiguous z-slabs, no
+data-path collective on the way in, one all-gather at the end.  The product's sharding code
+runs unchanged with gloo standing in for RCCL and the CPU oracle for the HIP engine."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from hmvec_amd.dist import slab_bounds
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_slab_bounds():
+    assert [slab_bounds(32, 8, r) for r in (0, 3, 7)] == [(0, 4), (12, 16), (28, 32)]
+    assert slab_bounds(20, 1, 0) == (0, 20)
+    with pytest.raises(ValueError):
+        slab_bounds(20, 8, 0)          # equal-count all-gather needs nz % world == 0
+
+
+def test_two_rank_zslab_gather_matches_full_grid(tmp_path):
+    port = free_port()
+    worker = os.path.join(REPO, "tests", "helpers", "shard_worker.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode()[-2000:]
+    full = np.load(tmp_path / "full.npz")
+    for rank in range(2):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        assert set(got.files) == set(full.files)
+        for k in full.files:
+            # every stage is independent along z: slab results are bit-identical;
+            # the secant mass conversion is allowed its documented <=7e-15
+            assert got[k].shape == full[k].shape
+            assert np.allclose(got[k], full[k], rtol=1e-12, atol=0), k
