@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmgrid.so")
+LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
 ABI_VERSION = 1
 COMM_ID_BYTES = 128
 

@@ -344,8 +344,8 @@ __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
 // row constants (c, r_s, 1/m_c: a log and two divisions) are computed once per thread
 // instead of once per point; sin(c x) comes from the angle-difference identity on the two
 // sincos the Si/Ci asymptotics need anyway; k is the fast axis -> coalesced 8 B stores.
-// ktile = k values per single-wave workgroup (a multiple of 64)
-__global__ __launch_bounds__(64) void nfw_kernel(const SiciTable* __restrict__ T, int ktile, int nm, int nk,
+// ktile = k values per workgroup (a multiple of the block size)
+__global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ T, int ktile, int nm, int nk,
                                                   const double* __restrict__ cs,
                                                   const double* __restrict__ rss,
                                                   const double* __restrict__ zs,
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void nfw_kernel(const SiciTable* __restrict__ T
     const double inv_mc = 1.0 / (log(opc) - c / opc);
     const double inv_opc2 = 1.0 / (opc * opc);
     double* __restrict__ dst = uk + (size_t)row * nk;
-    for (int k = k_lo + threadIdx.x; k < k_hi; k += 64) {
+    for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
         const double x = ks[k] * rs * z1;
         const double xc = opc * x;
         double s1, c1, s2, c2;
@@ -1117,7 +1117,10 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
         for (int p = 0; p < NPAIR; ++p) P[p][v] = 0.0;
     }
     const size_t zrow = (size_t)z * A.nm;
-#pragma unroll 2
+#ifndef HMG_PB_UNROLL
+#define HMG_PB_UNROLL 2
+#endif
+#pragma unroll HMG_PB_UNROLL
     for (int m = wv; m < A.nm; m += MS) {
         const double* __restrict__ c = A.coef + (zrow + m) * (size_t)STRIDE;
         vec_t t[NT];
@@ -1433,15 +1436,20 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
                      const double* zs, const double* ks, double* uk) {
     REQUIRE(c && cs && rs && zs && ks && uk, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
-    // 16 k per lane amortises the row constants best; shrink the tile for thin z-slabs so the
-    // grid still covers the chip several times over (~28 resident waves per CU)
-    int ktile = 1024;
-    while (ktile > 256 && (size_t)nz * nm * ((nk + ktile - 1) / ktile) < (size_t)c->num_cu * 28 * 4) ktile >>= 1;
+    // 16 k per thread amortises the row constants (a log and two divisions); shrink the tile for
+    // thin z-slabs so the grid still covers the chip several times over (~28 waves per CU)
+    int threads = 256, ktile = 4096;
+    if (const char* e = getenv("HMG_NFW_THREADS")) threads = atoi(e);
+    if (const char* e = getenv("HMG_NFW_KTILE")) ktile = atoi(e);
+    REQUIRE(threads == 64 || threads == 128 || threads == 256, "HMG_NFW_THREADS must be 64/128/256");
+    REQUIRE(ktile >= threads && ktile % threads == 0, "HMG_NFW_KTILE must be a multiple of the block size");
+    const size_t slots = (size_t)c->num_cu * 28 * 64 / threads;
+    while (ktile > 4 * threads && (size_t)nz * nm * ((nk + ktile - 1) / ktile) < slots * 4) ktile >>= 1;
     const size_t blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
     REQUIRE(blocks <= 2147483647u, "grid too large");
     int stop = -1;
     if (bracket_open(c, HMG_KERNEL_NFW, &stop)) return 1;
-    hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(64), 0, c->stream, c->d_sici, ktile, nm, nk, cs, rs, zs, ks, uk);
+    hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(threads), 0, c->stream, c->d_sici, ktile, nm, nk, cs, rs, zs, ks, uk);
     HIP_TRY(hipGetLastError());
     if (bracket_close(c, stop)) return 1;
     return 0;
@@ -1772,7 +1780,9 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
     // thin z-slabs: narrower k tiles so that every CU still gets a workgroup
     if (vec2 && (long)((nk + 127) / 128) * nz < c->num_cu) vec2 = false;
-    int ms_split = 8;
+    int ms_split = 4;
+    if (const char* e = getenv("HMG_PB_MS")) ms_split = atoi(e);
+    REQUIRE(ms_split >= 1 && ms_split <= 8, "HMG_PB_MS must be 1..8");
     while (ms_split > 1 && ms_split > nm) ms_split >>= 1;
 #define PB_V(NT_, NTR_) return vec2 ? launch_power_batch<NT_, NTR_, 2>(c, A, nz, ms_split) \
                                     : launch_power_batch<NT_, NTR_, 1>(c, A, nz, ms_split);
