@@ -77,6 +77,7 @@ SIGNATURES = {
                   _D, _D, _P, _P],
     "hmg_power_batch": [_P, _I, _I, _I, _I, C.POINTER(Tracer), _I, C.POINTER(_I), C.POINTER(_I),
                         _P, _P, _P, _P, _P, _P, _D, _D, C.POINTER(_P), C.POINTER(_P)],
+    "hmg_limber": [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "hmg_comm_unique_id": [C.c_char * COMM_ID_BYTES],
     "hmg_comm_init": [_P, C.c_char * COMM_ID_BYTES, _I, _I],
     "hmg_comm_allgather": [_P, _P, _P, _Z],

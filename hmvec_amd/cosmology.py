@@ -16,9 +16,10 @@ from scipy.special import hyp2f1
 from . import _native as nat
 from .background import AnalyticBackground, CambBackground, C_KMS
 from .params import default_params
-from .quadrature import simpson_weights
+from .quadrature import simpson_weights, trapz_weights
 
 cspeed = C_KMS
+_trapz = getattr(np, "trapezoid", None) or np.trapz
 
 
 def a2z(a):
@@ -257,3 +258,99 @@ class Cosmology(object):
         if ret_pk:
             return self._d_sigma2.numpy(), ks_sigma2[None, None, :], self.sPzk[:, None, :]
         return self._d_sigma2.numpy()
+
+    # ------------------------------------------------------------------ Limber projections (row N1)
+    def lensing_window(self, ezs, zs, dndz=None):
+        """Lensing convergence window W(z) (hmvec/cosmology.py:506-534).  `zs` is a single
+        source redshift (delta function) or the grid on which `dndz` is given."""
+        ezs = np.asarray(ezs, dtype=np.float64)
+        zs = np.array(zs, dtype=np.float64).reshape(-1)
+        H0 = self.h_of_z(0.0)
+        H = self.h_of_z(ezs)
+        chis = self.comoving_radial_distance(ezs)
+        chistar = self.comoving_radial_distance(zs)
+        if zs.size == 1:
+            assert dndz is None
+            integral = (chistar - chis) / chistar
+            integral[ezs > zs] = 0
+        else:
+            dndz = np.asarray(dndz, dtype=np.float64)
+            dndz = dndz / _trapz(dndz, zs)
+            integrand = (chistar[None, :] - chis[:, None]) / chistar[None, :] * dndz[None, :]
+            integrand[zs[None, :] < ezs[:, None]] = 0
+            integral = _trapz(integrand, zs, axis=-1)
+        return 1.5 * self.omm0 * H0 ** 2.0 * (1.0 + ezs) * chis / H * integral
+
+    def C_kk(self, ells, zs, ks, Pmm, lzs1=None, ldndz1=None, lzs2=None, ldndz2=None, lwindow1=None,
+             lwindow2=None):
+        """hmvec/cosmology.py:563-568."""
+        if lwindow1 is None:
+            lwindow1 = self.lensing_window(zs, lzs1, ldndz1)
+        if lwindow2 is None:
+            lwindow2 = self.lensing_window(zs, lzs2, ldndz2)
+        chis = self.comoving_radial_distance(zs)
+        hzs = self.h_of_z(zs)
+        return self.limber_integral(ells, zs, ks, Pmm, zs, lwindow1, lwindow2, hzs, chis)
+
+    def C_kg(self, ells, zs, ks, Pgm, gzs, gdndz=None, lzs=None, ldndz=None, lwindow=None):
+        """hmvec/cosmology.py:536-547."""
+        gzs = np.array(gzs, dtype=np.float64).reshape(-1)
+        Wz1s = self.lensing_window(gzs, lzs, ldndz) if lwindow is None else lwindow
+        chis = self.comoving_radial_distance(gzs)
+        hzs = self.h_of_z(gzs)
+        if gzs.size > 1:
+            Wz2s = gdndz / _trapz(gdndz, gzs)
+        else:
+            Wz2s = 1.0
+        return self.limber_integral(ells, zs, ks, Pgm, gzs, Wz1s, Wz2s, hzs, chis)
+
+    def C_gg(self, ells, zs, ks, Pgg, gzs, gdndz=None, zmin=None, zmax=None):
+        """hmvec/cosmology.py:549-561."""
+        gzs = np.asarray(gzs, dtype=np.float64)
+        chis = self.comoving_radial_distance(gzs)
+        hzs = self.h_of_z(gzs)
+        if gzs.size > 1:
+            Wz1s = Wz2s = gdndz / _trapz(gdndz, gzs)
+        else:
+            dchi = self.comoving_radial_distance(zmax) - self.comoving_radial_distance(zmin)
+            Wz1s = 1.0
+            Wz2s = 1.0 / dchi / hzs
+        return self.limber_integral(ells, zs, ks, Pgg, gzs, Wz1s, Wz2s, hzs, chis)
+
+    def C_ky(self, ells, zs, ks, Pym, lzs1=None, ldndz1=None, lzs2=None, ldndz2=None, lwindow1=None):
+        """hmvec/cosmology.py:585-589."""
+        if lwindow1 is None:
+            lwindow1 = self.lensing_window(zs, lzs1, ldndz1)
+        return self.limber_integral(ells, zs, ks, Pym, zs, lwindow1, 1, self.h_of_z(zs),
+                                    self.comoving_radial_distance(zs))
+
+    def C_yy(self, ells, zs, ks, Ppp, dndz=None, zmin=None, zmax=None):
+        """hmvec/cosmology.py:591-597."""
+        return self.limber_integral(ells, zs, ks, Ppp, zs, 1, 1, self.h_of_z(zs),
+                                    self.comoving_radial_distance(zs))
+
+    def limber_integral(self, ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis):
+        """C(ell) = int dz (H/c) W1 W2 P(z, k=(ell+1/2)/chi) / chi^2 on the GPU (hmg_limber);
+        argument meaning as hmvec/cosmology.py:867-904.  Pzks may be a numpy (nz,nk) array or
+        a DeviceArray already resident in HBM."""
+        ells = np.ascontiguousarray(ells, dtype=np.float64)
+        zs = np.atleast_1d(np.asarray(zs, dtype=np.float64))
+        ks = np.asarray(ks, dtype=np.float64)
+        gzs = np.atleast_1d(np.asarray(gzs, dtype=np.float64)).reshape(-1)
+        hzs = np.array(hzs, dtype=np.float64).reshape(-1)
+        chis = np.array(chis, dtype=np.float64).reshape(-1)
+        W1 = np.array(Wz1s, dtype=np.float64).reshape(-1)
+        W2 = np.array(Wz2s, dtype=np.float64).reshape(-1)
+        pref = (hzs * W1 * W2 / chis ** 2.0) + 0.0 * gzs
+        if zs.size == 1:
+            kev = (ells[:, None] + 0.5) / chis[None, :]
+            if np.any(kev < ks[0]) or np.any(kev > ks[-1]):
+                raise ValueError("A value in x_new is outside the interpolation range.")  # interp1d
+        wz = trapz_weights(gzs) if gzs.size > 1 else np.ones(1)
+        ctx = self._ctx()
+        dP = Pzks if isinstance(Pzks, nat.DeviceArray) else ctx.upload(np.asarray(Pzks, dtype=np.float64))
+        d = [ctx.upload(a) for a in (ells, zs, ks, gzs, pref, chis + 0.0 * gzs, wz)]
+        out = ctx.empty((ells.size,))
+        ctx.call("hmg_limber", ells.size, d[0].ptr, zs.size, ks.size, d[1].ptr, d[2].ptr, dP.ptr,
+                 gzs.size, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr, out.ptr)
+        return out.numpy().reshape(np.shape(ells))

@@ -145,6 +145,26 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubl
     return r;
 }
 
+// Sum N per-thread values over a 1-D block with two barriers in total (instead of 2N):
+// wave shuffles, one LDS exchange of N x (#waves) partials, fixed-order final sum.  The
+// results are valid in threads 0..N-1 (thread i holds the total of v[i]).  lds >= N*16 doubles.
+template <int N>
+__device__ __forceinline__ double block_sum_multi(const double (&v)[N], double* lds) {
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+    const int nw = (blockDim.x + WAVE - 1) >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double s = wave_sum(v[i]);
+        if (lane == 0) lds[i * 16 + w] = s;
+    }
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x < N)
+        for (int k = 0; k < nw; ++k) r += lds[threadIdx.x * 16 + k];
+    return r;
+}
+
 // ---------------------------------------------------------------- K1: sigma^2(z,m) (A2)
 // sigma2[z,m] = sum_j wq[j] P[z,j] W(kq[j] R[m])^2 is a small contraction over the 10^4-point
 // k' grid.  Each block owns an MT x ZT register tile of (mass, redshift) outputs: per k' it
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
                                                      const double* __restrict__ wq,
                                                      const double* __restrict__ R, double tswitch,
                                                      double* __restrict__ out) {
-    __shared__ double lds[16];
+    __shared__ double lds[MT * ZT * 16];
     const int m0 = blockIdx.x * MT, z0 = blockIdx.y * ZT;
     // blockIdx.z selects a contiguous segment of the k' grid; partial sums go to
     // out + blockIdx.z * nz * nm and are combined in a fixed order by sigma2_combine_kernel
@@ -199,14 +219,16 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
             for (int i = 0; i < MT; ++i) acc[i][zi] += a[i] * p;
         }
     }
+    double flat[MT * ZT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int zi = 0; zi < ZT; ++zi) {
-            const double tot = block_sum(acc[i][zi], lds);
-            if (threadIdx.x == 0 && m0 + i < nm && z0 + zi < nz)
-                out[(size_t)(z0 + zi) * nm + (m0 + i)] = tot;
-        }
+        for (int zi = 0; zi < ZT; ++zi) flat[i * ZT + zi] = acc[i][zi];
+    const double tot = block_sum_multi<MT * ZT>(flat, lds);
+    if (threadIdx.x < MT * ZT) {
+        const int i = threadIdx.x / ZT, zi = threadIdx.x - i * ZT;
+        if (m0 + i < nm && z0 + zi < nz) out[(size_t)(z0 + zi) * nm + (m0 + i)] = tot;
+    }
 }
 
 __global__ void sigma2_combine_kernel(int n, int parts, const double* __restrict__ partial,
@@ -1214,6 +1236,53 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
     }
 }
 
+// ---------------------------------------------------------------- N1: Limber integral
+// C_ell = int dz pref(z) P(z, k=(ell+1/2)/chi(z)) with P bilinear in (z,k) on the model grid,
+// clamped to the grid box (hmvec/cosmology.py:867-904; the degree-1 fitpack spline the
+// reference evaluates clamps its arguments).  One thread per multipole, loop over the nz_w
+// window redshifts; wz = trapezoid weights over those redshifts (or {1} for a delta window).
+__global__ void limber_kernel(int nells, const double* __restrict__ ells, int nz, int nk,
+                              const double* __restrict__ zs, const double* __restrict__ ks,
+                              const double* __restrict__ P, int ngz, const double* __restrict__ gzs,
+                              const double* __restrict__ pref, const double* __restrict__ chis,
+                              const double* __restrict__ wz, double* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nells) return;
+    const double ell = ells[e];
+    double acc = 0.0;
+    for (int g = 0; g < ngz; ++g) {
+        double k = (ell + 0.5) / chis[g];
+        k = fmin(fmax(k, ks[0]), ks[nk - 1]);
+        int lo = 0, hi = nk - 1;            // largest i with ks[i] <= k, capped at nk-2
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ks[mid] <= k) lo = mid; else hi = mid;
+        }
+        const int i = lo;
+        const double tx = (k - ks[i]) / (ks[i + 1] - ks[i]);
+        double val;
+        if (nz == 1) {
+            val = (1.0 - tx) * P[i] + tx * P[i + 1];
+        } else {
+            double z = fmin(fmax(gzs[g], zs[0]), zs[nz - 1]);
+            int jl = 0, jh = nz - 1;
+            while (jh - jl > 1) {
+                const int mid = (jl + jh) >> 1;
+                if (zs[mid] <= z) jl = mid; else jh = mid;
+            }
+            const int j = jl;
+            const double ty = (z - zs[j]) / (zs[j + 1] - zs[j]);
+            const double* r0 = P + (size_t)j * nk;
+            const double* r1 = r0 + nk;
+            val = (1.0 - tx) * (1.0 - ty) * r0[i] + tx * (1.0 - ty) * r0[i + 1] +
+                  (1.0 - tx) * ty * r1[i] + tx * ty * r1[i + 1];
+        }
+        acc += wz[g] * (val * pref[g]);
+    }
+    out[e] = acc;
+}
+
 }  // namespace hmg
 
 // ------------------------------------------------------------------------------------------
@@ -1366,13 +1435,14 @@ int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const doubl
                const double* wq, const double* R, double tswitch, double* out) {
     REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
-    // Tile so that the launch fills the chip: big (mass x redshift) register tiles when the
-    // grid is large, small tiles plus a split of the k' axis for thin z-slabs (multi-GPU).
-    int mt, zt;
-    if (nz > 4) { mt = 2; zt = 8; } else if (nz > 2) { mt = 2; zt = 4; } else { mt = 4; zt = 2; }
-    const long blocks = (long)((nm + mt - 1) / mt) * ((nz + zt - 1) / zt);
+    // (mass x redshift) register tiles: wider in z when there are more redshifts.  The k' axis
+    // is always cut into the same number of segments (a function of nq only), so the summation
+    // order of every output - and therefore the result, bit for bit - does not depend on how
+    // many redshifts a z-slab holds (multi-GPU runs reproduce the single-GPU numbers).
+    int zt;
+    if (nz > 4) zt = 8; else if (nz > 2) zt = 4; else zt = 2;
     int ksplit = 1;
-    while (ksplit < 8 && blocks * ksplit < 1024 && nq / (ksplit * 2) >= 256) ksplit *= 2;
+    while (ksplit < 4 && nq / (ksplit * 2) >= 1024) ksplit *= 2;
     double* dst = out;
     if (ksplit > 1) {
         if (ensure_scratch(c, 4, (size_t)ksplit * nz * nm * 8)) return 1;
@@ -1699,8 +1769,10 @@ int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hm
     // enough waves to cover the chip: MS mass slices per block
     const int V = vec2 ? 2 : 1;
     const long blocks = (long)((nk + 64 * V - 1) / (64 * V)) * nz;
+    // the number of mass slices fixes the summation order over m: keep it a function of nm only,
+    // so that a z-slab run (multi-GPU) reproduces the full-grid numbers bit for bit
+    (void)blocks;
     int ms_split = 8;
-    if (blocks * 8 < (long)c->num_cu * 16) ms_split = 16;
     while (ms_split > 1 && ms_split > nm) ms_split >>= 1;
 #define PW_CASE(NT_)                                                      \
     case NT_:                                                             \
@@ -1780,7 +1852,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
     // thin z-slabs: narrower k tiles so that every CU still gets a workgroup
     if (vec2 && (long)((nk + 127) / 128) * nz < c->num_cu) vec2 = false;
-    int ms_split = 4;
+    int ms_split = 8;   // fixed (function of nm only): summation order independent of the slab size
     if (const char* e = getenv("HMG_PB_MS")) ms_split = atoi(e);
     REQUIRE(ms_split >= 1 && ms_split <= 8, "HMG_PB_MS must be 1..8");
     while (ms_split > 1 && ms_split > nm) ms_split >>= 1;
@@ -1803,6 +1875,17 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
 #undef PB_NTR
 #undef PB_V
     return fail("hmg_power_batch", "unreachable", __FILE__, __LINE__);
+}
+
+int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const double* zs,
+               const double* ks, const double* P, int ngz, const double* gzs, const double* pref,
+               const double* chis, const double* wz, double* out) {
+    REQUIRE(c && ells && zs && ks && P && gzs && pref && chis && wz && out, "NULL argument");
+    REQUIRE(nells > 0 && nz >= 1 && nk >= 2 && ngz >= 1, "bad sizes");
+    hipLaunchKernelGGL(limber_kernel, grid1d((size_t)nells, 128), dim3(128), 0, c->stream, nells, ells, nz,
+                       nk, zs, ks, P, ngz, gzs, pref, chis, wz, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // ---- RCCL ------------------------------------------------------------------------------------

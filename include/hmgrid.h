@@ -206,6 +206,16 @@ int hmg_power_batch(hmg_ctx* ctx, int nz, int nm, int nk, int ntr, const hmg_tra
                     const double* d_ks, const double* d_Pzk, double rho_m0, double kstar,
                     double* const* h_P1h, double* const* h_P2h);
 
+/* ---- N1: Limber projection ------------------------------------------------------------------
+ * Replaces limber_integral (hmvec/cosmology.py:867-904): for every multipole,
+ *   C_ell = sum_g wz[g] * pref[g] * P(z = gzs[g], k = (ell + 1/2)/chis[g]),
+ * P bilinear in (z,k) on the (nz,nk) grid and clamped to it; pref = H W1 W2 / chi^2 built by
+ * the caller; wz = trapezoid weights over gzs (a single 1 for a delta-function window).
+ * nz == 1 does 1-D interpolation in k.                                                        */
+int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, const double* d_zs,
+               const double* d_ks, const double* d_Pzk, int ngz, const double* d_gzs,
+               const double* d_pref, const double* d_chis, const double* d_wz, double* d_out);
+
 /* ---- z-slab gather over RCCL/xGMI -------------------------------------------------
  * One communicator per context.  The 128-byte id comes from hmg_comm_unique_id on rank 0
  * and is distributed by the caller (file, socket, MPI, ...).                                     */

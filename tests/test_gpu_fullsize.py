@@ -1,0 +1,104 @@
+"""Config 3 (BASELINE.json configs[2]: 32 x 512 x 4096, NFW + electron + HOD) at FULL size on
+the GPU, checked through size-independent properties of the path plus an oracle sub-sample:
+batched == per-pair, z-slab == full grid, the 2-halo consistency limit, 1-halo damping,
+affine dependence on an injected bias, profile limits, sortedness of inputs irrelevant."""
+import numpy as np
+import pytest
+
+from conftest import merged_params, power_close
+
+pytestmark = pytest.mark.gpu
+
+NZ, NM, NK, NXS = 32, 512, 4096, 5000
+PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"),
+         ("nfw", "electron"), ("g", "nfw"), ("g", "electron")]
+
+
+def grids():
+    return np.linspace(0.01, 3.0, NZ), np.geomspace(2e10, 1e17, NM), np.geomspace(1e-4, 100, NK)
+
+
+def build(zs, ms, ks):
+    import hmvec_amd as hm
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=NXS)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    return h
+
+
+@pytest.fixture(scope="module")
+def full():
+    zs, ms, ks = grids()
+    return build(zs, ms, ks)
+
+
+def test_batched_equals_per_pair_full_size(full):
+    o1, o2 = full.power_device_batch(PAIRS)
+    for (a, b), d1, d2 in zip(PAIRS, o1, o2):
+        assert np.allclose(d1.numpy(), full.get_power_1halo(a, b), rtol=1e-12, atol=0), (a, b)
+        assert np.allclose(d2.numpy(), full.get_power_2halo(a, b), rtol=1e-12, atol=0), (a, b)
+
+
+def test_zslab_equals_full_grid(full):
+    """Every stage is independent along z: a slab model reproduces its rows."""
+    zs, ms, ks = grids()
+    lo, hi = 12, 16
+    slab = build(zs[lo:hi], ms, ks)
+    assert np.array_equal(slab.sigma2, full.sigma2[lo:hi])
+    assert np.array_equal(slab.nzm, full.nzm[lo:hi])
+    for a, b in (("nfw", "nfw"), ("g", "g")):
+        assert np.array_equal(slab.get_power(a, b), full.get_power(a, b)[lo:hi]), (a, b)
+    for a, b in (("electron", "electron"), ("g", "electron")):
+        assert np.allclose(slab.get_power(a, b), full.get_power(a, b)[lo:hi], rtol=1e-13, atol=0), (a, b)
+
+
+def test_two_halo_consistency_and_damping(full):
+    zs, ms, ks = grids()
+    p1, p2 = full.get_power_1halo("nfw"), full.get_power_2halo("nfw")
+    assert np.allclose(p2[:, 0] / full.Pzk[:, 0], 1.0, rtol=1e-5)              # P2h -> P_lin (hmvec.py:566-572)
+    bg = full.hods["g"]["bg"]
+    pg = full.get_power_2halo("g")
+    assert np.allclose(pg[:, 0] / full.Pzk[:, 0], bg ** 2, rtol=1e-5)          # -> b_g^2 P_lin
+    assert np.all(p1[:, ks < 1e-3] < 1e-3 * p2[:, ks < 1e-3])                   # 1h damped below k* (hmvec.py:526)
+    assert np.all(np.isfinite(p1)) and np.all(np.isfinite(p2)) and np.all(p1 >= 0)
+
+
+def test_two_halo_affine_in_injected_bias(full):
+    zs = grids()[0]
+    one = np.ones(zs.size)
+    P = [full.get_power_2halo("g", "nfw", b1_in=b * one, b2_in=one) for b in (1.0, 2.0, 3.0)]
+    d1, d2 = P[1] - P[0], P[2] - P[1]
+    assert np.allclose(d1, d2, rtol=1e-10, atol=1e-12 * np.max(np.abs(P[2])))
+
+
+def test_profile_limits(full):
+    u = full.uk_profiles["nfw"]
+    assert np.allclose(u[:, :, 0], 1.0, atol=1e-5)            # u(k->0) = 1
+    assert np.max(np.abs(u)) <= 1.0 + 1e-12
+    ue = full.uk_profiles["electron"]
+    assert np.all(np.isfinite(ue)) and np.max(np.abs(ue)) < 1.1
+    # mass-normalised; the k->0 value is the first FFT mode (left=u[first k>0], hmvec/fft.py:107),
+    # i.e. u at k x ~ 0.3, a little below 1
+    assert np.all(ue[:, :, 0] > 0.5) and np.all(ue[:, :, 0] < 1.05)
+
+
+def test_against_oracle_subsample(full):
+    """Two redshifts of the full grid through the CPU oracle (seconds) vs the same rows on the GPU."""
+    from hmvec_amd.params import battaglia_defaults
+    from oracle import hmref
+    zs, ms, ks = grids()
+    sel = np.array([3, 27])
+    z = zs[sel]
+    p = merged_params()
+    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+    ci = hmref.CosmoInputs(h=full.h, omm0=full.omm0, ombh2=p["ombh2"],
+                           rho_crit_0=float(full.rho_critical_z(0.0)), rho_crit_zs=full.rho_critical_z(z),
+                           Pzk=full.Pzk[sel], sPzk=full.sPzk[sel], ks_sigma2=ksig, h_of_z_zs=full.h_of_z(z))
+    o = hmref.RefHaloModel(ci, z, ks, ms, p)
+    o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], NXS, 20)
+    o.add_hod("g", mthresh=10 ** 10.5 + z * 0.0)
+    assert np.max(np.abs(full.uk_profiles["nfw"][sel] - o.uk_profiles["nfw"])) < 1e-12
+    assert np.max(np.abs(full.uk_profiles["electron"][sel] - o.uk_profiles["electron"])) < 1e-12
+    for a, b in PAIRS:
+        ok, w = power_close(full.get_power(a, b)[sel], o.get_power(a, b))
+        assert ok, (a, b, w)

@@ -187,3 +187,25 @@ def test_batched_equals_per_pair(case):
     ok, _ = power_close(tot[("g", "electron")], g["P_tot_g_electron"])
     assert ok
     assert np.array_equal(tot[("g", "electron")], tot[("electron", "g")])
+
+
+def test_limber_projections():
+    """Row N1: C_kk / C_kg / C_gg and the lensing window against the reference (case_c)."""
+    g = load_golden("case_c")
+    h = build_gpu(g)
+    meta = g["meta"]
+    lz, gzs = meta["limber"]["lzs"], meta["limber"]["gzs"]
+    zs, ks, ells = g["zs"], g["ks"], g["ells"]
+    assert rel_err(h.lensing_window(zs, lz), g["lensing_window"]) < 1e-13
+    Pmm = g["P1h_nfw_nfw"] + g["P2h_nfw_nfw"]
+    Pgm = g["P1h_nfw_g"] + g["P2h_nfw_g"]
+    Pgg = g["P1h_g_g"] + g["P2h_g_g"]
+    assert rel_err(h.C_kk(ells, zs, ks, Pmm, lzs1=lz, lzs2=lz), g["C_kk"]) < 1e-12
+    assert rel_err(h.C_kg(ells, zs, ks, Pgm, gzs=gzs, lzs=lz), g["C_kg"]) < 1e-12
+    gz, gd = g["gz_dndz"]
+    assert rel_err(h.C_kg(ells, zs, ks, Pgm, gzs=gz, gdndz=gd, lzs=lz), g["C_kg_dndz"]) < 1e-12
+    assert rel_err(h.C_gg(ells, zs, ks, Pgg, gzs=gz, gdndz=gd), g["C_gg_dndz"]) < 1e-12
+    # end to end from the GPU spectra (Config 5 shape): same tolerance as the spectra themselves
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    ckk = h.C_kk(ells, zs, ks, h.get_power("nfw"), lzs1=lz, lzs2=lz)
+    assert np.allclose(ckk, g["C_kk"], rtol=1e-8)
