@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
     const double opc = 1.0 + c;
     const double inv_mc = 1.0 / (log(opc) - c / opc);
     const double inv_opc2 = 1.0 / (opc * opc);
+    const double ln_opc = log(opc);
     double* __restrict__ dst = uk + (size_t)row * nk;
     for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
         const double x = ks[k] * rs * z1;
@@ -401,11 +402,15 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
         const double zx = rcp_fast(x * x);   // 1/x^2
         const double zc = zx * inv_opc2;     // 1/xc^2
         double si1, ci1, si2, ci2;
-        sici_fast(T, x, s1, c1, zx, si1, ci1);
-        sici_fast(T, xc, s2, c2, zc, si2, ci2);
+        bool sm1, sm2;
+        sici_fast(T, x, s1, c1, zx, si1, ci1, sm1);
+        sici_fast(T, xc, s2, c2, zc, si2, ci2, sm2);
+        // Ci((1+c)x) - Ci(x): x <= xc, so the cases are (small,small), (small,large), (large,large)
+        double dci = ci2 - ci1;
+        if (sm1) dci += sm2 ? ln_opc : -(EULER_GAMMA + log(x));
         const double scx = s2 * c1 - c2 * s1;  // sin(c x) = sin((1+c)x - x)
         // sin(cx)/((1+c)x) = scx * xc / xc^2
-        dst[k] = (s1 * (si2 - si1) - scx * (xc * zc) + c1 * (ci2 - ci1)) * inv_mc;
+        dst[k] = (s1 * (si2 - si1) - scx * (xc * zc) + c1 * dci) * inv_mc;
     }
 }
 
@@ -1440,9 +1445,11 @@ int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const doubl
     // order of every output - and therefore the result, bit for bit - does not depend on how
     // many redshifts a z-slab holds (multi-GPU runs reproduce the single-GPU numbers).
     int zt;
-    if (nz > 4) zt = 8; else if (nz > 2) zt = 4; else zt = 2;
+    if (nz > 8) zt = 16; else if (nz > 4) zt = 8; else if (nz > 2) zt = 4; else zt = 2;
+    if (const char* e = getenv("HMG_SIG_ZT")) zt = atoi(e);
     int ksplit = 1;
     while (ksplit < 4 && nq / (ksplit * 2) >= 1024) ksplit *= 2;
+    if (const char* e = getenv("HMG_SIG_KSPLIT")) ksplit = atoi(e);
     double* dst = out;
     if (ksplit > 1) {
         if (ensure_scratch(c, 4, (size_t)ksplit * nz * nm * 8)) return 1;
@@ -1455,7 +1462,8 @@ int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const doubl
         hipLaunchKernelGGL((sigma2_kernel<MT_, ZT_>), grid, dim3(256), 0, c->stream, nz, nm, nq, sP, \
                            kq, wq, R, tswitch, dst);                                           \
     } while (0)
-    if (zt == 8) SIG_LAUNCH(2, 8);
+    if (zt == 16) SIG_LAUNCH(2, 16);
+    else if (zt == 8) SIG_LAUNCH(2, 8);
     else if (zt == 4) SIG_LAUNCH(2, 4);
     else SIG_LAUNCH(4, 2);
 #undef SIG_LAUNCH
