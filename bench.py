@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--nxs", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-pair", action="store_true", help="six hmg_power launches instead of one hmg_power_batch")
+    ap.add_argument("--detail", action="store_true",
+                    help="also record per-stage and NFW/FFT-kernel HIP events in the timed region (each event "
+                         "costs a few us of stream time; off by default so they do not perturb `value`)")
     ap.add_argument("--cpu-sample-nz", type=int, default=16)
     args = ap.parse_args()
 
@@ -126,10 +129,10 @@ def main():
         """One full pass of the hot path.  base = first event slot of this step (timed region
         only): [0..5] stage marks, [6,7] mass-integral kernel, [8,9] NFW kernel, [10,11] FFT chain."""
         def mark(i):
-            if base is not None:
+            if base is not None and args.detail:
                 ctx.record(base + i)
         def bracket(name, i):
-            if base is not None:
+            if base is not None and args.detail:
                 ctx.call("hmg_bracket_next", BR[name], base + i, base + i + 1)
         mark(0)
         h.init_mass_function(ms)
@@ -142,7 +145,8 @@ def main():
         mark(3)
         h.add_hod("g", mthresh=mthr, ignore_existing=True)
         mark(4)
-        spec.run((base + 6, base + 7) if base is not None else None, batched=not args.per_pair)
+        spec.run((base + 6, base + 7) if base is not None and (args.detail or not args.per_pair) else None,
+                 batched=not args.per_pair)
         mark(5)
 
     for _ in range(W):
@@ -165,12 +169,13 @@ def main():
     kern_ms = {"power": 0.0, "nfw": 0.0, "fft": 0.0}
     for s in range(K):
         base = 16 + s * SLOTS_PER_STEP
-        for j in range(5):
-            stage_ms[j] += ctx.elapsed_ms(base + j, base + j + 1)
         if not args.per_pair:
             kern_ms["power"] += ctx.elapsed_ms(base + 6, base + 7)
-        kern_ms["nfw"] += ctx.elapsed_ms(base + 8, base + 9)
-        kern_ms["fft"] += ctx.elapsed_ms(base + 10, base + 11)
+        if args.detail:
+            for j in range(5):
+                stage_ms[j] += ctx.elapsed_ms(base + j, base + j + 1)
+            kern_ms["nfw"] += ctx.elapsed_ms(base + 8, base + 9)
+            kern_ms["fft"] += ctx.elapsed_ms(base + 10, base + 11)
     stage_ms /= K
     kern_ms = {k: v / K for k, v in kern_ms.items()}
     B, nm_, nk_, nxs = nzl * ms.size, ms.size, ks.size, args.nxs
@@ -183,9 +188,11 @@ def main():
         "fft": 2 * 8.0 * B * nxs + 2 * 16.0 * B * (nxs // 2 + 1) + tens_bytes,
     }
     if args.per_pair:
+        if not args.detail:
+            sys.exit("--per-pair needs --detail (the six launches are timed through the stage events)")
         kern_ms["power"] = stage_ms[4]
         alg["power"] = float(sum(power_alg_bytes(nzl, nm_, nk_, d) for d in PAIR_TENSORS))
-    gbs = {k: alg[k] / (kern_ms[k] * 1e-3) / 1e9 for k in alg}
+    gbs = {k: (alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else None) for k in alg}
 
     # HBM traffic of the roofline kernel from the committed PMC profile (same config only)
     traffic = None
@@ -218,15 +225,17 @@ def main():
                          "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "(2*FETCH+WRITE)*1024 bytes per launch)" if traffic else None,
                          "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"]},
-            "kernels": {
+        }
+        if args.detail:
+            out["kernels"] = {
                 "nfw_kernel": {"bound": "fp64-valu", "ms": kern_ms["nfw"], "alg_GBps": gbs["nfw"],
                                "note": "2 Si/Ci rational evaluations + 2 sincos per 8 B written"},
-                "profile_fft_chain": {"bound": "hbm/infinity-cache", "ms": kern_ms["fft"], "alg_GBps": gbs["fft"],
-                                      "note": "integrand + rocFFT R2C + fused interpolation, chunked to stay in the 256 MiB Infinity Cache"},
-            },
-            "stages_ms": dict(zip(["mass_function", "nfw", "battaglia_fft", "hod", "spectra+gather"],
-                                  stage_ms.tolist())),
-        }
+                "profile_fused_kernel": {"bound": "fp64-valu + LDS", "ms": kern_ms["fft"],
+                                         "alg_GBps": 8.0 * B * nk_ / (kern_ms["fft"] * 1e-3) / 1e9,
+                                         "note": "integrand + in-LDS packed-real FFT + k-interpolation; HBM traffic = output row only"},
+            }
+            out["stages_ms"] = dict(zip(["mass_function", "nfw", "battaglia_fft", "hod", "spectra+gather"],
+                                        stage_ms.tolist()))
         if world == 1 and not args.no_cpu_baseline:
             cb, sel, ref = cpu_baseline(zs, ms, ks, args.cpu_sample_nz, args.nxs)
             res = spec.results()

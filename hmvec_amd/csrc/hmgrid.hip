@@ -630,7 +630,7 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
 }
 
 template <int NT, int MAXB, int MAXP>
-__global__ __launch_bounds__(NT) void profile_fused_kernel(FusedArgs A) {
+__global__ __launch_bounds__(NT, (MAXB <= 2 ? 8 : 4)) void profile_fused_kernel(FusedArgs A) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
     // scratch and the broadcast mass norm.

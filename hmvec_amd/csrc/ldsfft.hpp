@@ -107,12 +107,20 @@ template <int R>
 HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int j, cplx* v) {
     const int k = j % Ns;
     const int stride = M / R;
-    const int tstep = k * (M / (Ns * R));
     v[0] = buf[j];
+    if (k == 0) {
+#pragma unroll
+        for (int t = 1; t < R; ++t) v[t] = buf[j + t * stride];
+        return;
+    }
+    // one table read (w = W^(k M/(Ns R))); the higher powers by complex multiplication
+    // (<= 3 products, a few ulp) instead of R-1 dependent trips to the L2-resident table
+    const cplx w1 = twM[k * (M / (Ns * R))];
+    cplx w = w1;
 #pragma unroll
     for (int t = 1; t < R; ++t) {
-        const cplx a = buf[j + t * stride];
-        v[t] = (k == 0) ? a : cmul(a, twM[t * tstep]);
+        v[t] = cmul(buf[j + t * stride], w);
+        if (t + 1 < R) w = cmul(w, w1);
     }
 }
 template <int R>
