@@ -951,9 +951,11 @@ template <int V> struct VecT;
 template <> struct VecT<1> { using type = double; };
 template <> struct VecT<2> { using type = double2; };
 
+
 template <int V> __device__ __forceinline__ double vget(const typename VecT<V>::type& v, int i);
 template <> __device__ __forceinline__ double vget<1>(const double& v, int) { return v; }
 template <> __device__ __forceinline__ double vget<2>(const double2& v, int i) { return i ? v.y : v.x; }
+
 
 // grid (ceil(nk/(64 V)), nz); block 64*MS threads: lane -> V consecutive k, wave -> an
 // interleaved slice of the mass axis.  Each wave streams 512 B*V per tensor per mass bin
