@@ -166,41 +166,55 @@ __device__ __forceinline__ double block_sum_multi(const double (&v)[N], double* 
 }
 
 // ---------------------------------------------------------------- K1: sigma^2(z,m) (A2)
-// sigma2[z,m] = sum_j wq[j] P[z,j] W(kq[j] R[m])^2 is a small contraction over the 10^4-point
-// k' grid.  Each block owns an MT x ZT register tile of (mass, redshift) outputs: per k' it
-// evaluates MT windows (one sincos each, the expensive part) and loads ZT spectrum values,
-// then does MT*ZT FMAs, so both the sincos and the P(k) loads are amortised; nothing of
-// shape (nz,nm,nq) is ever materialised (the reference builds 1.3 GB temporaries).
-template <int MT, int ZT>
-__global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
-                                                     const double* __restrict__ sP,
-                                                     const double* __restrict__ kq,
-                                                     const double* __restrict__ wq,
-                                                     const double* __restrict__ R, double tswitch,
-                                                     double* __restrict__ out) {
-    __shared__ double lds[MT * ZT * 16];
-    const int m0 = blockIdx.x * MT, z0 = blockIdx.y * ZT;
-    // blockIdx.z selects a contiguous segment of the k' grid; partial sums go to
-    // out + blockIdx.z * nz * nm and are combined in a fixed order by sigma2_combine_kernel
-    const int seg = (nq + gridDim.z - 1) / gridDim.z;
-    const int j_lo = blockIdx.z * seg, j_hi = min(nq, j_lo + seg);
-    out += (size_t)blockIdx.z * nz * nm;
-    double r[MT], acc[MT][ZT];
-    const double* prow[ZT];
+// sigma2[z,m] = sum_j P[z,j] * A[j,m],  A[j,m] = wq[j] W(kq[j] R[m])^2, is the one dense
+// contraction of the path (nz x nm x 10^4): it runs on the fp64 matrix cores.  A wavefront
+// owns a 16-mass tile, 16*ZB redshifts and one segment of the k' axis; per step of four k'
+// every lane evaluates ONE window value - which is directly its element of the MFMA B operand
+// (B[k = lane>>4][col = lane&15]) - loads its element(s) of P from a [k'][z] transposed,
+// zero-padded copy (A[row = lane&15][k = lane>>4], 128 B coalesced per 16 lanes), and issues
+// ZB v_mfma_f64_16x16x4_f64.  The window (one sincos) is therefore evaluated exactly once per
+// (m, k') for up to 32 redshifts, and the nz-fold multiply-accumulate is off the vector ALU.
+// The k' axis is cut into a number of segments that depends on nq only, so the summation
+// order - and the result, bit for bit - is the same for a z-slab and for the full grid; the
+// per-segment partial sums are combined in order by sigma2_combine_kernel.  Nothing of shape
+// (nz,nm,nq) is materialised (the reference builds 1.3 GB temporaries here).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int SIG_SEG_LEN = 80;    // k' values per segment (multiple of 16)
+
+// out[c][r] = in[r][c] for r < rows, zero for rows <= r < rows_pad
+__global__ void transpose_pad_kernel(int rows, int rows_pad, int cols, const double* __restrict__ in,
+                                     double* __restrict__ out /*[cols][rows_pad]*/) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows_pad * cols) return;
+    const int c = (int)(i / rows_pad), r = (int)(i - (size_t)c * rows_pad);
+    out[i] = r < rows ? in[(size_t)r * cols + c] : 0.0;
+}
+
+template <int ZB>
+__global__ __launch_bounds__(64) void sigma2_mfma_kernel(int nz, int nzp, int nm, int nq,
+                                                         const double* __restrict__ PT /*[nq][nzp]*/,
+                                                         const double* __restrict__ kq,
+                                                         const double* __restrict__ wq,
+                                                         const double* __restrict__ R, double tswitch,
+                                                         double* __restrict__ partial /*[seg][nz][nm]*/) {
+    const int lane = threadIdx.x, col = lane & 15, kk = lane >> 4;
+    const int m = blockIdx.x * 16 + col;
+    const int seg = blockIdx.y;
+    const int z0 = blockIdx.z * (16 * ZB);
+    const double r = R[min(m, nm - 1)];
+    d4_t acc[ZB];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) r[i] = R[min(m0 + i, nm - 1)];
+    for (int b = 0; b < ZB; ++b) acc[b] = d4_t{0.0, 0.0, 0.0, 0.0};
+    const int q_lo = seg * SIG_SEG_LEN, q_hi = min(nq, q_lo + SIG_SEG_LEN);
+    // four MFMA k-steps per trip: four independent window evaluations per lane in flight
+    for (int q0 = q_lo; q0 < q_hi; q0 += 16) {
+        double a[4];
+        int qi[4];
 #pragma unroll
-    for (int i = 0; i < ZT; ++i) prow[i] = sP + (size_t)min(z0 + i, nz - 1) * nq;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < ZT; ++j) acc[i][j] = 0.0;
-    for (int j = j_lo + threadIdx.x; j < j_hi; j += blockDim.x) {
-        const double kj = kq[j], wj = wq[j];
-        double a[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const double kR = kj * r[i];
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + 4 * u + kk;
+            qi[u] = min(q, nq - 1);
+            const double kR = kq[qi[u]] * r;
             double w;
             if (kR < tswitch) {
                 const double xx = kR * kR;
@@ -208,36 +222,44 @@ __global__ __launch_bounds__(256) void sigma2_kernel(int nz, int nm, int nq,
             } else {
                 double s, c;
                 if (kR < 1.0e9) sincos_fast(kR, s, c); else sincos(kR, &s, &c);
-                w = 3.0 * (s - kR * c) / (kR * kR * kR);
+                w = 3.0 * (s - kR * c) * rcp_fast(kR * kR * kR);
             }
-            a[i] = wj * (w * w);
+            a[u] = (q < q_hi) ? wq[qi[u]] * (w * w) : 0.0;
         }
 #pragma unroll
-        for (int zi = 0; zi < ZT; ++zi) {
-            const double p = prow[zi][j];
+        for (int u = 0; u < 4; ++u) {
+            const double* __restrict__ prow = PT + (size_t)qi[u] * nzp + z0 + col;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i][zi] += a[i] * p;
+            for (int b = 0; b < ZB; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(prow[16 * b], a[u], acc[b], 0, 0, 0);
         }
     }
-    double flat[MT * ZT];
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    if (m < nm) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int b = 0; b < ZB; ++b)
 #pragma unroll
-        for (int zi = 0; zi < ZT; ++zi) flat[i * ZT + zi] = acc[i][zi];
-    const double tot = block_sum_multi<MT * ZT>(flat, lds);
-    if (threadIdx.x < MT * ZT) {
-        const int i = threadIdx.x / ZT, zi = threadIdx.x - i * ZT;
-        if (m0 + i < nm && z0 + zi < nz) out[(size_t)(z0 + zi) * nm + (m0 + i)] = tot;
+            for (int rg = 0; rg < 4; ++rg) {
+                const int z = z0 + 16 * b + kk + 4 * rg;
+                if (z < nz) partial[((size_t)seg * nz + z) * nm + m] = acc[b][rg];
+            }
     }
 }
 
-__global__ void sigma2_combine_kernel(int n, int parts, const double* __restrict__ partial,
-                                      double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_p partial[p][i] in a fixed order: 4 wavefronts per 64 outputs take interleaved
+// segments, then add up through LDS (wave 0, in wave order).
+__global__ __launch_bounds__(256) void sigma2_combine_kernel(int n, int parts,
+                                                             const double* __restrict__ partial,
+                                                             double* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     double s = 0.0;
-    for (int p = 0; p < parts; ++p) s += partial[(size_t)p * n + i];
-    out[i] = s;
+    if (i < n)
+        for (int p = w; p < parts; p += 4) s += partial[(size_t)p * n + i];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) out[i] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // ---------------------------------------------------------------- K2: mass function (A3/A4)
@@ -734,6 +756,11 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? 8 : 4)) void profile_fused_kernel(
 }
 
 // ---------------------------------------------------------------- K7: HOD (H1-H3)
+// 10^y and x^p through exp2/log2 (one transcendental each instead of the ~6x longer generic
+// pow); relative error <= ~|y| * 8e-16, far inside the 1e-9 gate on the HOD arrays.
+__device__ __forceinline__ double pow10_fast(double y) { return exp2(y * 3.32192809488736234787); }
+__device__ __forceinline__ double powr_fast(double x, double p) { return exp2(p * log2(x)); }
+
 struct ShmrSet {
     double Ms0, Msa, M1, M1a, b0, ba, g0, ga, d0, da;
 };
@@ -750,7 +777,7 @@ __device__ __forceinline__ double shmr_log10mh(double lms, double a, const ShmrS
     const double gamma = s.g0 + s.ga * am1;
     const double delta = s.d0 + s.da * am1;
     const double d = lms - lMs0;
-    return -0.5 + lM1 + beta * d + pow(10.0, delta * d) / (1.0 + pow(10.0, -gamma * d));
+    return -0.5 + lM1 + beta * d + pow10_fast(delta * d) / (1.0 + pow10_fast(-gamma * d));
 }
 
 constexpr int SHMR_N = 4000;
@@ -782,8 +809,8 @@ __global__ __launch_bounds__(1024) void hod_kernel(int nm, HodDev P, const doubl
     __syncthreads();
     const double thr = lthr[z];
     const double mthr_halo = shmr_log10mh(thr, a, S);
-    const double Msat = 1.0e12 * P.Bsat * pow(10.0, (mthr_halo - 12.0) * P.betasat);
-    const double Mcut = 1.0e12 * P.Bcut * pow(10.0, (mthr_halo - 12.0) * P.betacut);
+    const double Msat = 1.0e12 * P.Bsat * pow10_fast((mthr_halo - 12.0) * P.betasat);
+    const double Mcut = 1.0e12 * P.Bcut * pow10_fast((mthr_halo - 12.0) * P.betacut);
     const double denom = sqrt(2.0) * P.sig;
     double acc_n = 0.0, acc_b = 0.0;
     for (int m = threadIdx.x; m < nm; m += blockDim.x) {
@@ -808,8 +835,8 @@ __global__ __launch_bounds__(1024) void hod_kernel(int nm, HodDev P, const doubl
             }
         }
         const double nc = 0.5 * (1.0 - erf((thr - lmstar) / denom));
-        const double mass = pow(10.0, lmh);
-        const double ns = nc * pow(mass / Msat, P.alphasat) * exp(-Mcut / mass);
+        const double mass = pow10_fast(lmh);
+        const double ns = nc * powr_fast(mass / Msat, P.alphasat) * exp(-Mcut / mass);
         double nn, cn;
         if (P.corr == 0) {
             nn = (fabs(nc) <= 1.0e-8) ? 0.0 : (ns * ns) / nc;   // np.isclose(Nc, 0)
@@ -1442,38 +1469,27 @@ int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const doubl
                const double* wq, const double* R, double tswitch, double* out) {
     REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
-    // (mass x redshift) register tiles: wider in z when there are more redshifts.  The k' axis
-    // is always cut into the same number of segments (a function of nq only), so the summation
-    // order of every output - and therefore the result, bit for bit - does not depend on how
-    // many redshifts a z-slab holds (multi-GPU runs reproduce the single-GPU numbers).
-    int zt;
-    if (nz > 8) zt = 16; else if (nz > 4) zt = 8; else if (nz > 2) zt = 4; else zt = 2;
-    if (const char* e = getenv("HMG_SIG_ZT")) zt = atoi(e);
-    int ksplit = 1;
-    while (ksplit < 4 && nq / (ksplit * 2) >= 1024) ksplit *= 2;
-    if (const char* e = getenv("HMG_SIG_KSPLIT")) ksplit = atoi(e);
-    double* dst = out;
-    if (ksplit > 1) {
-        if (ensure_scratch(c, 4, (size_t)ksplit * nz * nm * 8)) return 1;
-        dst = (double*)c->scratch[4];
-    }
-#define SIG_LAUNCH(MT_, ZT_)                                                                   \
-    do {                                                                                       \
-        dim3 grid((nm + MT_ - 1) / MT_, (nz + ZT_ - 1) / ZT_, ksplit);                         \
-        REQUIRE(grid.y <= 65535, "nz too large");                                             \
-        hipLaunchKernelGGL((sigma2_kernel<MT_, ZT_>), grid, dim3(256), 0, c->stream, nz, nm, nq, sP, \
-                           kq, wq, R, tswitch, dst);                                           \
-    } while (0)
-    if (zt == 16) SIG_LAUNCH(2, 16);
-    else if (zt == 8) SIG_LAUNCH(2, 8);
-    else if (zt == 4) SIG_LAUNCH(2, 4);
-    else SIG_LAUNCH(4, 2);
-#undef SIG_LAUNCH
-    if (ksplit > 1) {
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(sigma2_combine_kernel, grid1d((size_t)nz * nm, 256), dim3(256), 0, c->stream,
-                           nz * nm, ksplit, (const double*)dst, out);
-    }
+    const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
+    const int zb = nz > 16 ? 2 : 1;
+    const int ztile = 16 * zb;
+    const int nzp = (nz + ztile - 1) / ztile * ztile;
+    if (ensure_scratch(c, 4, (size_t)nseg * nz * nm * 8 + (size_t)nq * nzp * 8)) return 1;
+    double* partial = (double*)c->scratch[4];
+    double* PT = partial + (size_t)nseg * nz * nm;
+    hipLaunchKernelGGL(transpose_pad_kernel, grid1d((size_t)nzp * nq, 256), dim3(256), 0, c->stream, nz, nzp,
+                       nq, sP, PT);
+    HIP_TRY(hipGetLastError());
+    dim3 grid((nm + 15) / 16, nseg, nzp / ztile);
+    REQUIRE(grid.y <= 65535 && grid.z <= 65535, "grid too large");
+    if (zb == 2)
+        hipLaunchKernelGGL(sigma2_mfma_kernel<2>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
+                           (const double*)PT, kq, wq, R, tswitch, partial);
+    else
+        hipLaunchKernelGGL(sigma2_mfma_kernel<1>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
+                           (const double*)PT, kq, wq, R, tswitch, partial);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sigma2_combine_kernel, grid1d((size_t)nz * nm, 64), dim3(256), 0, c->stream,
+                       nz * nm, nseg, (const double*)partial, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
