@@ -1,0 +1,96 @@
+"""Edge cases of the HIP path against the CPU oracle: degenerate and ragged grid sizes, FFT
+lengths that take the workgroup-FFT path, the rocFFT fallback (odd length, prime factor > 5,
+too long for LDS), user-supplied profiles, and C-ABI argument validation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import merged_params, power_close
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_for(h, zs, ks, ms, nxs, xmax):
+    from hmvec_amd.params import battaglia_defaults
+    from oracle import hmref
+    p = merged_params()
+    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+    ci = hmref.CosmoInputs(h=h.h, omm0=h.omm0, ombh2=p["ombh2"], rho_crit_0=float(h.rho_critical_z(0.0)),
+                           rho_crit_zs=h.rho_critical_z(zs), Pzk=h.Pzk, sPzk=h.sPzk, ks_sigma2=ksig,
+                           h_of_z_zs=h.h_of_z(zs))
+    o = hmref.RefHaloModel(ci, zs, ks, ms, p)
+    o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], nxs, xmax)
+    o.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    return o
+
+
+@pytest.mark.parametrize("nz,nm,nk", [(1, 2, 1), (1, 5, 3), (3, 7, 65), (2, 64, 130), (5, 3, 2)])
+def test_ragged_grid_sizes(nz, nm, nk):
+    import hmvec_amd as hm
+    zs = np.linspace(0.2, 2.2, nz)
+    ms = np.geomspace(1e11, 1e16, nm)
+    ks = np.geomspace(1e-3, 30, nk) if nk > 1 else np.array([0.3])
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", nxs=200, xmax=20)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    o = oracle_for(h, zs, ks, ms, 200, 20)
+    assert np.max(np.abs(h.uk_profiles["nfw"] - o.uk_profiles["nfw"])) < 1e-12
+    assert np.max(np.abs(h.uk_profiles["electron"] - o.uk_profiles["electron"])) < 1e-12
+    for a, b in (("nfw", "nfw"), ("g", "electron"), ("g", "g"), ("electron", "nfw")):
+        ok, w = power_close(h.get_power(a, b), o.get_power(a, b))
+        assert ok, (a, b, w)
+    tot = h.get_power_all([("nfw", "electron"), ("g", "g")])
+    ok, _ = power_close(tot[("g", "g")], o.get_power("g", "g"))
+    assert ok
+
+
+@pytest.mark.parametrize("nxs", [16, 30, 100, 600, 14, 45, 22, 25000])
+def test_fft_lengths_fused_and_fallback(nxs):
+    """16, 30, 100, 600: workgroup FFT (radix 5/4/3/2, incl. an odd half-length); 14, 22: prime
+    factor 7/11 -> rocFFT; 45: odd length -> rocFFT; 25000: too long for LDS -> rocFFT."""
+    import hmvec_amd as hm
+    zs = np.array([0.3, 1.4])
+    ms = np.geomspace(1e12, 1e15, 6)
+    ks = np.geomspace(1e-3, 30, 33)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", nxs=nxs, xmax=20)
+    o = oracle_for(h, zs, ks, ms, nxs, 20)
+    assert np.max(np.abs(h.uk_profiles["electron"] - o.uk_profiles["electron"])) < 1e-12
+
+
+def test_user_supplied_profile_and_ms_none():
+    import hmvec_amd as hm
+    zs = np.array([0.5, 1.0])
+    ms = np.geomspace(1e12, 1e15, 8)
+    ks = np.geomspace(1e-2, 10, 16)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    u = np.exp(-np.outer(np.geomspace(0.1, 2.0, 8), ks) ** 2)[None] * np.ones((2, 1, 1))
+    h.uk_profiles["custom"] = u                      # numpy in -> uploaded
+    assert "custom" in h.uk_profiles and np.array_equal(h.uk_profiles["custom"], u)
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    w = (ms[:, None] * u / h.rho_matter_z(0)) ** 2
+    ref = trapz(h.nzm[..., None] * w, ms[:, None], axis=-2) * (1 - np.exp(-(ks / 0.01) ** 2))
+    assert np.allclose(h.get_power_1halo("custom"), ref, rtol=1e-12)
+    h2 = hm.HaloModel(zs, ks, ms=None, skip_nfw=True, accuracy="low", engine="analytic")
+    assert len(h2.uk_profiles) == 0 and h2.Pzk.shape == (2, 16)
+
+
+def test_c_abi_rejects_bad_arguments():
+    from hmvec_amd import _native as nat
+    ctx = nat.Context(0)
+    lib = ctx.lib
+    assert lib.hmg_sigma2(ctx.handle, 2, 2, 8, None, None, None, None, 0.01, None) != 0
+    assert b"NULL" in lib.hmg_last_error()
+    d = ctx.empty((4,))
+    assert lib.hmg_massfn(ctx.handle, 0, 4, None, d.ptr, d.ptr, d.ptr, None, d.ptr, d.ptr) != 0
+    par = nat.MassFnParams(mode=7)
+    assert lib.hmg_massfn(ctx.handle, 1, 4, C.byref(par), d.ptr, d.ptr, d.ptr, None, d.ptr, d.ptr) != 0
+    assert b"unknown mass function" in lib.hmg_last_error()
+    assert lib.hmg_lane_set(ctx.handle, 99) != 0
+    h = C.c_void_p()
+    assert lib.hmg_ctx_create(12345, C.byref(h)) != 0
+    assert b"out of range" in lib.hmg_last_error()
+    with pytest.raises(nat.NativeError):
+        ctx.call("hmg_event_record", -5)
+    ctx.close()
