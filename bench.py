@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--nxs", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-pair", action="store_true", help="six hmg_power launches instead of one hmg_power_batch")
+    ap.add_argument("--limber", action="store_true",
+                    help="Config 5: after the timed region also time C_kk and C_kg at 2000 multipoles "
+                         "(lzs=2.5, gzs=0.8) on the gathered spectra, rank 0; reported as extra fields")
     ap.add_argument("--detail", action="store_true",
                     help="also record per-stage and NFW/FFT-kernel HIP events in the timed region (each event "
                          "costs a few us of stream time; off by default so they do not perturb `value`)")
@@ -194,6 +197,25 @@ def main():
         alg["power"] = float(sum(power_alg_bytes(nzl, nm_, nk_, d) for d in PAIR_TENSORS))
     gbs = {k: (alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else None) for k in alg}
 
+    limber = None
+    if args.limber and rank == 0:
+        full = hm.Cosmology(dict(h.p), accuracy="low", engine="analytic")
+        full.ctx = ctx
+        ells = np.linspace(100, 6000, 2000)
+        iP = {p: i for i, p in enumerate(PAIRS)}
+        def total(pair):
+            i = iP[pair]
+            return spec.full[2 * i].numpy() + spec.full[2 * i + 1].numpy()
+        Pmm, Pgm = total(("nfw", "nfw")), total(("g", "nfw"))
+        full.C_kk(ells, zs, ks, Pmm, lzs1=2.5, lzs2=2.5)          # warm-up (uploads, first launch)
+        ctx.sync()
+        t1 = time.perf_counter()
+        ckk = full.C_kk(ells, zs, ks, Pmm, lzs1=2.5, lzs2=2.5)
+        ckg = full.C_kg(ells, zs, ks, Pgm, gzs=0.8, lzs=2.5)
+        limber = {"ells": 2000, "C_kk+C_kg_ms": (time.perf_counter() - t1) * 1e3,
+                  "C_kk[0]": float(ckk[0]), "C_kg[0]": float(ckg[0]),
+                  "note": "host wall incl. window functions, H2D of P(z,k) and D2H of C_ell"}
+
     # HBM traffic of the roofline kernel from the committed PMC profile (same config only)
     traffic = None
     default_cfg = (args.nz, args.nm, args.nk, args.nxs) == (32, 512, 4096, 5000) and world == 1 and not args.per_pair
@@ -226,6 +248,8 @@ def main():
                                            "(2*FETCH+WRITE)*1024 bytes per launch)" if traffic else None,
                          "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"]},
         }
+        if limber is not None:
+            out["limber"] = limber
         if args.detail:
             out["kernels"] = {
                 "nfw_kernel": {"bound": "fp64-valu", "ms": kern_ms["nfw"], "alg_GBps": gbs["nfw"],
