@@ -102,5 +102,15 @@ class CambBackground:
         self.results = camb.get_background(self.pars)
         self.YHe = self.pars.YHe
 
+    def pk_interpolator(self, zs, kmax, var="total", nonlinear=False):
+        """camb.get_matter_power_interpolator with the reference's arguments
+        (hmvec/cosmology.py:775-786)."""
+        import camb
+        from camb import model
+        cvar = {"weyl": model.Transfer_Weyl, "total": "delta_tot", "cb": "delta_nonu"}[var]
+        return camb.get_matter_power_interpolator(self.pars, nonlinear=nonlinear, hubble_units=False,
+                                                  k_hunit=False, kmax=kmax, var1=cvar, var2=cvar,
+                                                  zmax=zs[-1])
+
     def __getattr__(self, name):
         return getattr(self.results, name)

@@ -214,13 +214,46 @@ class Cosmology(object):
         pref = 8 * np.pi ** 2 * self.params["As"] / 25.0 / omh2 ** 2.0 * cspeed ** 4.0
         return pref * kfac[None, :] * Dz ** 2.0 * tk ** 2.0
 
-    def P_lin(self, ks, zs, knorm=1e-4, kmax=None):
-        raise NotImplementedError("accuracy='medium' needs a CAMB P(k) provider (SURVEY §8f N3)")
+    # ------------------------------------------------------------------ Boltzmann-code P(k) (row N3)
+    def get_pk_interpolator(self, zs, kmax, var="weyl", nonlinear=False, **kwargs):
+        """P(z,k) interpolator from the background provider (hmvec/cosmology.py:772-809).  The
+        provider must offer ``pk_interpolator(zs, kmax, var, nonlinear)`` returning an object
+        with CAMB's ``.P(zs, ks, grid=True)``; ``CambBackground`` does, the analytic one does not."""
+        if not hasattr(self._background, "pk_interpolator"):
+            raise NotImplementedError(
+                "this background provider has no Boltzmann-code P(k): use accuracy='low' "
+                "(Eisenstein-Hu) or a provider with pk_interpolator() such as CambBackground")
+        return self._background.pk_interpolator(np.asarray(zs), kmax, var.lower(), nonlinear)
 
-    P_lin_slow = P_lin
+    def P_lin(self, ks, zs, knorm=1e-4, kmax=None):
+        """EH98 shape normalised to the provider's P(knorm, z) — accuracy='medium'
+        (hmvec/cosmology.py:353-374)."""
+        zs = np.asarray(zs)
+        ks = np.asarray(ks)
+        tk = self.Tk(ks, "eisenhu_osc")
+        if kmax is None:
+            kmax = ks.max()
+        if knorm >= kmax:
+            raise ValueError
+        PK = self.get_pk_interpolator(zs, kmax=kmax, var="total", nonlinear=False)
+        pnorm = PK.P(zs, knorm, grid=True)
+        tnorm = self.Tk(knorm, "eisenhu_osc") * knorm ** (self.params["ns"])
+        plin = (pnorm / tnorm) * tk ** 2.0 * ks ** (self.params["ns"])
+        return (self.as8 ** 2.0) * plin
+
+    def P_lin_slow(self, ks, zs, kmax=None):
+        """Provider P(k) evaluated directly — accuracy='high' (hmvec/cosmology.py:376-382)."""
+        zs = np.asarray(zs)
+        ks = np.asarray(ks)
+        if kmax is None:
+            kmax = ks.max()
+        PK = self.get_pk_interpolator(zs, kmax=kmax, var="total", nonlinear=False)
+        return (self.as8 ** 2.0) * PK.P(zs, ks, grid=True)
 
     def _get_matter_power(self, zs, ks, nonlinear=False):
-        raise NotImplementedError("CAMB matter power is outside the analytic provider (SURVEY §8f N3)")
+        """hmvec/cosmology.py:227-229."""
+        PK = self.get_pk_interpolator(zs, kmax=ks.max(), var="total", nonlinear=nonlinear)
+        return (self.as8 ** 2.0) * PK.P(zs, ks, grid=True)
 
     # ------------------------------------------------------------------ sigma^2 on the GPU
     def _ctx(self):

@@ -91,3 +91,40 @@ def test_engine_and_accuracy_errors():
         Cosmology(engine="bogus")
     with pytest.raises(ValueError):
         Cosmology({"sigma8": 0.8}, accuracy="low", engine="analytic")
+
+
+class _FakePkBackground(AnalyticBackground):
+    """Provider with a Boltzmann-code-like P(k): the EH spectrum scaled by a z-dependent factor,
+    exposed through the CAMB interpolator interface (.P(zs, ks, grid=True))."""
+
+    def __init__(self, cos, scale):
+        p = cos.p
+        super().__init__(p["H0"], p["ombh2"], p["omch2"])
+        self._cos, self._scale = cos, scale
+
+    def pk_interpolator(self, zs, kmax, var="total", nonlinear=False):
+        cos, scale = self._cos, self._scale
+
+        class PK:
+            @staticmethod
+            def P(z, k, grid=True):
+                z, k = np.atleast_1d(z), np.atleast_1d(k)
+                return cos.P_lin_approx(k, z) * scale(z)[:, None]
+        return PK
+
+
+def test_medium_accuracy_through_provider_seam():
+    """Row N3: accuracy='medium'/'high' work with any provider that offers pk_interpolator();
+    the EH-shape renormalisation of hmvec/cosmology.py:353-374 is reproduced."""
+    base = Cosmology(accuracy="low", engine="analytic")
+    scale = lambda z: 1.0 + 0.1 * np.asarray(z)        # noqa: E731
+    zs, ks = np.array([0.0, 0.7, 2.0]), np.geomspace(1e-3, 10, 50)
+    cos = Cosmology(accuracy="medium", background=_FakePkBackground(base, scale))
+    want = base.P_lin_approx(ks, zs) * scale(zs)[:, None]
+    # the reference normalises with T(knorm), not T(knorm)^2 (hmvec/cosmology.py:372): kept as is
+    tk_norm = float(base.Tk(np.array([1e-4]))[0])
+    assert rel_err(cos.P_lin(ks, zs), want * tk_norm) < 1e-12
+    assert rel_err(cos.P_lin_slow(ks, zs), want) < 1e-14
+    assert rel_err(cos._get_matter_power(zs, ks), want) < 1e-14
+    with pytest.raises(NotImplementedError):
+        Cosmology(accuracy="low", engine="analytic").get_pk_interpolator(zs, 10.0)
