@@ -36,8 +36,9 @@ def _tinker_alpha_table():
 class DeviceDict(MutableMapping):
     """name -> DeviceArray with numpy reads (lazy D2H, cached) and numpy writes (H2D)."""
 
-    def __init__(self, ctx_getter):
+    def __init__(self, ctx_getter, on_change=None):
         self._ctx_getter = ctx_getter
+        self._on_change = on_change or (lambda: None)
         self._dev = {}
         self._host = {}
 
@@ -47,6 +48,7 @@ class DeviceDict(MutableMapping):
     def set_dev(self, name, darr):
         self._dev[name] = darr
         self._host.pop(name, None)
+        self._on_change()
 
     def __getitem__(self, name):
         if name not in self._host:
@@ -62,6 +64,7 @@ class DeviceDict(MutableMapping):
     def __delitem__(self, name):
         del self._dev[name]
         self._host.pop(name, None)
+        self._on_change()
 
     def __contains__(self, name):      # Mapping's default would call __getitem__ (a D2H copy)
         return name in self._dev
@@ -138,8 +141,12 @@ class HaloModel(Cosmology):
         self._use_lanes = os.environ.get("HMG_LANES", "0") == "1"   # multi-stream overlap; off by default
         self._recorded = set()
 
-        self.uk_profiles = DeviceDict(self._ctx)
-        self.pk_profiles = DeviceDict(self._ctx)
+        # (name, name2) -> (state version, P1h, P2h): a fused launch yields both terms, so the
+        # usual get_power_1halo(a,b) followed by get_power_2halo(a,b) streams the tensors once
+        self._pcache = {}
+        self._version = 0
+        self.uk_profiles = DeviceDict(self._ctx, self._bump)
+        self.pk_profiles = DeviceDict(self._ctx, self._bump)
 
         if ms is not None:
             self.ms = np.asarray(ms, dtype=np.float64)
@@ -183,6 +190,10 @@ class HaloModel(Cosmology):
         return R_from_M(ms, self.rho_matter_z(0), delta=1.0)
 
     # ------------------------------------------------------------------ device plumbing
+    def _bump(self):
+        """Any change of profiles / HODs / mass function invalidates cached spectra."""
+        self._version = getattr(self, "_version", 0) + 1
+
     def _dev(self, key, builder):
         """Host array -> device, uploaded once per key (inputs of the path stay resident)."""
         if key not in self._dcache:
@@ -289,6 +300,7 @@ class HaloModel(Cosmology):
                 self._dcache.pop(k)
             self._ms_key = ms.copy()
         self.ms = ms
+        self._bump()
         if self.mode not in ("sheth-torman", "tinker"):
             raise NotImplementedError
         if self.mdef not in ("vir", "mean"):
@@ -571,6 +583,7 @@ class HaloModel(Cosmology):
 
         l10 = np.log10(np.asarray(mthresh, dtype=np.float64))
         dev = self._hod_device(("hod", name), l10, pparams, corr)
+        self._bump()
         self.hods[name] = HodEntry(dev, dict(satellite_profile=satellite_profile_name,
                                              central_profile=central_profile_name,
                                              log10mthresh=np.log10(mthresh[:, None])))
@@ -649,9 +662,6 @@ class HaloModel(Cosmology):
         a2, ka2 = self._tracer(name, "mph") if want2 else (a1, ka1)
         b2, kb2 = self._tracer(name2, "mph") if want2 else (b1, kb1)
         if want2:
-            for nm_ in (name, name2):
-                if self._tracer(nm_, "mph")[1] == "p":
-                    print("Check the consistency relation for tSZ")
             if b1_in is not None:
                 keep.append(self._ctx().upload(np.asarray(b1_in, dtype=np.float64).reshape(-1)))
                 a2.d_bias_override = keep[-1].ptr
@@ -695,9 +705,6 @@ class HaloModel(Cosmology):
             for i, (a, b) in enumerate(pairs):
                 self.power_device(a, b, out1=o1[i], out2=o2[i])
             return o1, o2
-        for n_ in names:
-            if kinds[n_] == "p":
-                print("Check the consistency relation for tSZ")
         # (a,b) and (b,a) are the same spectrum here: compute each unordered pair once
         uniq, alias = [], []
         for a, b in pairs:
@@ -725,23 +732,53 @@ class HaloModel(Cosmology):
     def get_power_all(self, pairs):
         """Extension of the reference API: {(name, name2): P_1h + P_2h} for several pairs in one
         pass over the profile tensors."""
+        seen = []
+        for a, b in pairs:
+            for nm_ in (a, a if b is None else b):
+                if nm_ not in seen:
+                    seen.append(nm_)
+        self._tsz_notice(*seen)
         o1, o2 = self.power_device_batch(pairs)
         return {tuple(p): a.numpy() + b.numpy() for p, a, b in zip(pairs, o1, o2)}
 
+    def _tsz_notice(self, *names):
+        """The reference prints this once per pressure tracer in every 2-halo evaluation
+        (hmvec/hmvec.py:544)."""
+        for nm_ in names:
+            if nm_ not in self.uk_profiles and nm_ in self.pk_profiles:
+                print("Check the consistency relation for tSZ")
+
+    def _power_cached(self, name, name2):
+        name2 = name if name2 is None else name2
+        ent = self._pcache.get((name, name2))
+        if ent is None or ent[0] != self._version:
+            d1, d2 = self.power_device(name, name2)
+            ent = (self._version, d1, d2)
+            self._pcache[(name, name2)] = ent
+        return ent[1], ent[2]
+
     def get_power(self, name, name2=None, verbose=False, b1=None, b2=None):
         """P_1h + P_2h in one pass (hmvec/hmvec.py:500-502)."""
-        d1, d2 = self.power_device(name, name2, b1, b2)
+        self._tsz_notice(name, name if name2 is None else name2)
+        if b1 is None and b2 is None:
+            d1, d2 = self._power_cached(name, name2)
+        else:
+            d1, d2 = self.power_device(name, name2, b1, b2)
         if verbose:
             self._print_consistency(name, name2)
         return d1.numpy() + d2.numpy()
 
     def get_power_1halo(self, name="nfw", name2=None):
         """hmvec/hmvec.py:504-526."""
-        return self.power_device(name, name2, want=("1h",))[0].numpy()
+        return self._power_cached(name, name2)[0].numpy()
 
     def get_power_2halo(self, name="nfw", name2=None, verbose=False, b1_in=None, b2_in=None):
         """hmvec/hmvec.py:528-572."""
-        out = self.power_device(name, name2, b1_in, b2_in, want=("2h",))[1].numpy()
+        self._tsz_notice(name, name if name2 is None else name2)
+        if b1_in is None and b2_in is None:
+            out = self._power_cached(name, name2)[1].numpy()
+        else:
+            out = self.power_device(name, name2, b1_in, b2_in, want=("2h",))[1].numpy()
         if verbose:
             self._print_consistency(name, name2)
         return out

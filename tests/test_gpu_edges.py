@@ -94,3 +94,28 @@ def test_c_abi_rejects_bad_arguments():
     with pytest.raises(nat.NativeError):
         ctx.call("hmg_event_record", -5)
     ctx.close()
+
+
+def test_spectrum_cache_is_invalidated_by_state_changes():
+    """get_power_1halo(a,b) + get_power_2halo(a,b) share one fused launch; any change of the
+    profiles / HOD / mass function must drop the cached pair."""
+    import hmvec_amd as hm
+    zs = np.array([0.4, 1.1])
+    ms = np.geomspace(1e12, 1e15, 12)
+    ks = np.geomspace(1e-2, 10, 20)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", nxs=200, xmax=20)
+    p1 = h.get_power_1halo("electron")
+    v = h._version
+    p2 = h.get_power_2halo("electron")
+    assert h._version == v and ("electron", "electron") in h._pcache
+    assert np.array_equal(h.get_power("electron"), p1 + p2)
+    h.add_battaglia_profile("electron", family="SH", nxs=200, xmax=20, ignore_existing=True)
+    q1 = h.get_power_1halo("electron")
+    assert not np.allclose(q1, p1)                       # recomputed with the new profile
+    h.uk_profiles["electron"] = np.ones((2, 12, 20))
+    assert not np.allclose(h.get_power_1halo("electron"), q1)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    g1 = h.get_power_1halo("g")
+    h.add_hod("g", mthresh=10 ** 11.5 + zs * 0.0, ignore_existing=True)
+    assert not np.allclose(h.get_power_1halo("g"), g1)
