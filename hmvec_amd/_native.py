@@ -221,6 +221,18 @@ class Context:
         check(getattr(self.lib, name)(self.handle, *args))
 
 
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide shared Context per device (streams, scratch, FFT tables are reused by
+    every HaloModel that is not given its own)."""
+    c = _default_ctx.get(device)
+    if c is None or not c.handle:
+        c = _default_ctx[device] = Context(device)
+    return c
+
+
 def ptr(x):
     """Device pointer of a DeviceArray or NULL."""
     return None if x is None else x.ptr

@@ -258,7 +258,7 @@ class Cosmology(object):
     # ------------------------------------------------------------------ sigma^2 on the GPU
     def _ctx(self):
         if getattr(self, "ctx", None) is None:
-            self.ctx = nat.Context(getattr(self, "_device", 0))
+            self.ctx = nat.default_context(getattr(self, "_device", 0))
         return self.ctx
 
     def _sigma2_device(self, R, sPzk, ks_sigma2):

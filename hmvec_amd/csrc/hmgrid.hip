@@ -97,6 +97,13 @@ struct hmg_ctx {
 
 static int rocfft_refcount = 0;
 
+// events are created on first use (a context rarely needs more than a handful of the slots)
+static int event_at(hmg_ctx* c, int slot, hipEvent_t* out) {
+    if (!c->ev[slot]) HIP_TRY(hipEventCreate(&c->ev[slot]));
+    *out = c->ev[slot];
+    return 0;
+}
+
 static int sync_all(hmg_ctx* c) {
     for (auto& st : c->lanes) HIP_TRY(hipStreamSynchronize(st));
     return 0;
@@ -1343,9 +1350,16 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
-    for (auto& st : c->lanes) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    {
+        // lane 0 carries the short dependent kernels (mass function, HOD, spectra): give it the
+        // highest priority so its workgroups are picked first whenever a slot frees up while a
+        // long kernel of another lane is draining
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically smallest = highest
+        for (int i = 0; i < HMG_LANES; ++i)
+            HIP_TRY(hipStreamCreateWithPriority(&c->lanes[i], hipStreamNonBlocking, i == 0 ? hi : lo));
+    }
     c->stream = c->lanes[0];
-    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     if (rocfft_refcount++ == 0) FFT_TRY(rocfft_setup());
     {
         const hmg::SiciTable t = hmg::sici_table_host();
@@ -1426,16 +1440,20 @@ int hmg_lane_set(hmg_ctx* c, int lane) {
 }
 int hmg_event_wait(hmg_ctx* c, int slot) {
     REQUIRE(c && slot >= 0 && slot < HMG_EVENT_SLOTS, "bad event slot");
+    if (!c->ev[slot]) return 0;   // never recorded: nothing to wait for
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev[slot], 0));
     return 0;
 }
 int hmg_event_record(hmg_ctx* c, int slot) {
     REQUIRE(c && slot >= 0 && slot < HMG_EVENT_SLOTS, "bad event slot");
-    HIP_TRY(hipEventRecord(c->ev[slot], c->stream));
+    hipEvent_t e;
+    if (event_at(c, slot, &e)) return 1;
+    HIP_TRY(hipEventRecord(e, c->stream));
     return 0;
 }
 int hmg_elapsed_ms(hmg_ctx* c, int s0, int s1, double* ms) {
     REQUIRE(c && ms && s0 >= 0 && s0 < HMG_EVENT_SLOTS && s1 >= 0 && s1 < HMG_EVENT_SLOTS, "bad event slot");
+    REQUIRE(c->ev[s0] && c->ev[s1], "event slot was never recorded");
     HIP_TRY(hipEventSynchronize(c->ev[s1]));
     float f = 0.f;
     HIP_TRY(hipEventElapsedTime(&f, c->ev[s0], c->ev[s1]));
@@ -1456,12 +1474,20 @@ static int bracket_open(hmg_ctx* c, int kid, int* stop_slot) {
     *stop_slot = -1;
     const int s0 = c->bracket[kid][0], s1 = c->bracket[kid][1];
     c->bracket[kid][0] = c->bracket[kid][1] = -1;
-    if (s0 >= 0) HIP_TRY(hipEventRecord(c->ev[s0], c->stream));
+    if (s0 >= 0) {
+        hipEvent_t e;
+        if (event_at(c, s0, &e)) return 1;
+        HIP_TRY(hipEventRecord(e, c->stream));
+    }
     *stop_slot = s1;
     return 0;
 }
 static int bracket_close(hmg_ctx* c, int stop_slot) {
-    if (stop_slot >= 0) HIP_TRY(hipEventRecord(c->ev[stop_slot], c->stream));
+    if (stop_slot >= 0) {
+        hipEvent_t e;
+        if (event_at(c, stop_slot, &e)) return 1;
+        HIP_TRY(hipEventRecord(e, c->stream));
+    }
     return 0;
 }
 
