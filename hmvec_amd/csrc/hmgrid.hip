@@ -1602,15 +1602,14 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
                      const double* zs, const double* ks, double* uk) {
     REQUIRE(c && cs && rs && zs && ks && uk, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
-    // 16 k per thread amortises the row constants (a log and two divisions); shrink the tile for
-    // thin z-slabs so the grid still covers the chip several times over (~28 waves per CU)
+    // 16 k per thread amortise the per-row prologue (a log, two divisions, the scalar loads of the
+    // series row); smaller tiles were measured slower at every grid size once the series made the
+    // per-point cost small
     int threads = 256, ktile = 4096;
     if (const char* e = getenv("HMG_NFW_THREADS")) threads = atoi(e);
     if (const char* e = getenv("HMG_NFW_KTILE")) ktile = atoi(e);
     REQUIRE(threads == 64 || threads == 128 || threads == 256, "HMG_NFW_THREADS must be 64/128/256");
     REQUIRE(ktile >= threads && ktile % threads == 0, "HMG_NFW_KTILE must be a multiple of the block size");
-    const size_t slots = (size_t)c->num_cu * 28 * 64 / threads;
-    while (ktile > 4 * threads && (size_t)nz * nm * ((nk + ktile - 1) / ktile) < slots * 4) ktile >>= 1;
     const size_t blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
     REQUIRE(blocks <= 2147483647u, "grid too large");
     if (ensure_scratch(c, 5, (size_t)nz * nm * NFW_NS * 8)) return 1;
