@@ -1664,7 +1664,10 @@ static int get_plan(hmg_ctx* c, int nxs, int batch, FftPlan** out) {
     return 0;
 }
 
-constexpr int FUSED_NT = 512;
+#ifndef HMG_FUSED_NT
+#define HMG_FUSED_NT 512
+#endif
+constexpr int FUSED_NT = HMG_FUSED_NT;   // threads per row workgroup of the fused profile kernel
 
 // Workgroup-FFT tables for a given nxs; returns nullptr (no error) when the fused kernel
 // cannot take this length.
