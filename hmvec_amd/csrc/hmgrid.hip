@@ -702,8 +702,11 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
     __syncthreads();
 }
 
+#ifndef HMG_FUSED_OCC
+#define HMG_FUSED_OCC 8
+#endif
 template <int NT, int MAXB, int MAXP>
-__global__ __launch_bounds__(NT, (MAXB <= 2 ? 8 : 4)) void profile_fused_kernel(FusedArgs A) {
+__global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_fused_kernel(FusedArgs A) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
     // scratch and the broadcast mass norm.
@@ -742,10 +745,12 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? 8 : 4)) void profile_fused_kernel(
     int Ns = 1;
     for (int ps = 0; ps < A.plan.npass; ++ps) {
         const int R = A.plan.radix[ps];
-        if (R == 5) fused_pass<NT, 5, MAXB>(buf, A.twM, M, Ns);
-        else if (R == 4) fused_pass<NT, 4, MAXB>(buf, A.twM, M, Ns);
-        else if (R == 3) fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns);
-        else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns);
+        // a pass whose butterflies fit one per thread uses the MAXB = 1 body (fewer live registers)
+        const bool one = (M / R) <= NT;
+        if (R == 5) { if (one) fused_pass<NT, 5, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 5, MAXB>(buf, A.twM, M, Ns); }
+        else if (R == 4) { if (one) fused_pass<NT, 4, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 4, MAXB>(buf, A.twM, M, Ns); }
+        else if (R == 3) { if (one) fused_pass<NT, 3, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns); }
+        else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns); }
         Ns *= R;
     }
     // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm, j = 1..M, into smem[0..M-1]
@@ -1747,6 +1752,7 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
             int rc;
             const int mb = FP->maxb, mp = FP->maxp;
             if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
+            else if (mb <= 2 && mp <= 3) rc = launch_fused<2, 3>(c, A, rows);   // nxs = 5000
             else if (mb <= 2 && mp <= 4) rc = launch_fused<2, 4>(c, A, rows);
             else rc = launch_fused<4, 8>(c, A, rows);
             if (rc) return 1;
