@@ -262,8 +262,18 @@ __global__ __launch_bounds__(256) void sigma2_combine_kernel(int n, int parts,
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     double s = 0.0;
-    if (i < n)
-        for (int p = w; p < parts; p += 4) s += partial[(size_t)p * n + i];
+    if (i < n) {
+        // loads are independent of the running sum: issue them eight at a time
+        int p = w;
+        for (; p + 28 < parts; p += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < parts; p += 4) s += partial[(size_t)p * n + i];
+    }
     red[w][lane] = s;
     __syncthreads();
     if (w == 0 && i < n) out[i] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
