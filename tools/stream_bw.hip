@@ -1,0 +1,63 @@
+// Diagnostic: practical HBM READ bandwidth on this MI355X for (a) a flat grid-stride stream
+// and (b) the access shape of hmg::power_batch_kernel (64 lanes x 16 B per row chunk, 8
+// wavefronts per block on interleaved rows, two tensors), with no arithmetic beyond a sum.
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/stream_bw.hip -o /tmp/stream_bw && /tmp/stream_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ void flat_read(const double2* __restrict__ a, size_t n, double* out) {
+    double s = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 v = a[i];
+        s += v.x + v.y;
+    }
+    if (s == 1.2345e-300) out[0] = s;
+}
+
+// grid (nk/128, nz), block 512: wave w reads rows m = w, w+8, ... of its z, chunk blockIdx.x
+__global__ __launch_bounds__(512) void shaped_read(const double* __restrict__ t0, const double* __restrict__ t1,
+                                                   int nm, int nk, double* out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, z = blockIdx.y;
+    const int k0 = (blockIdx.x * 64 + lane) * 2;
+    double s = 0.0;
+    for (int m = wv; m < nm; m += 8) {
+        const size_t off = ((size_t)z * nm + m) * nk + k0;
+        const double2 a = *reinterpret_cast<const double2*>(t0 + off);
+        const double2 b = *reinterpret_cast<const double2*>(t1 + off);
+        s += a.x * b.y + a.y * b.x;
+    }
+    if (s == 1.2345e-300) out[0] = s;
+}
+
+int main() {
+    const int nz = 32, nm = 512, nk = 4096;
+    const size_t n = (size_t)nz * nm * nk;
+    double *t0, *t1, *out;
+    CK(hipMalloc(&t0, n * 8)); CK(hipMalloc(&t1, n * 8)); CK(hipMalloc(&out, 8));
+    CK(hipMemset(t0, 0, n * 8)); CK(hipMemset(t1, 0, n * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double bytes = 2.0 * n * 8;
+    for (int variant = 0; variant < 3; ++variant) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 12; ++rep) {
+            CK(hipEventRecord(e0));
+            if (variant == 0) {
+                hipLaunchKernelGGL(flat_read, dim3(256 * 8), dim3(256), 0, 0, (const double2*)t0, n / 2, out);
+                hipLaunchKernelGGL(flat_read, dim3(256 * 8), dim3(256), 0, 0, (const double2*)t1, n / 2, out);
+            } else if (variant == 1) {
+                hipLaunchKernelGGL(flat_read, dim3(256 * 32), dim3(256), 0, 0, (const double2*)t0, n / 2, out);
+                hipLaunchKernelGGL(flat_read, dim3(256 * 32), dim3(256), 0, 0, (const double2*)t1, n / 2, out);
+            } else {
+                hipLaunchKernelGGL(shaped_read, dim3(nk / 128, nz), dim3(512), 0, 0, t0, t1, nm, nk, out);
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 1 && ms < best) best = ms;
+        }
+        const char* name[3] = {"flat grid-stride read, 2048 blocks", "flat grid-stride read, 8192 blocks", "power_batch access shape, no math"};
+        printf("%-40s %.4f ms  %.0f GB/s\n", name[variant], best, bytes / (best * 1e-3) / 1e9);
+    }
+    return 0;
+}
