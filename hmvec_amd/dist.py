@@ -141,3 +141,20 @@ class ShardedSpectra:
         """{(a,b): (P1h, P2h)} as numpy (nz_total, nk) arrays; blocks."""
         return {p: (self.full[2 * i].numpy(), self.full[2 * i + 1].numpy())
                 for i, p in enumerate(self.pairs)}
+
+
+def mthresh_from_ngal_global(zs_full, ks, ms, ngal_full, **model_kwargs):
+    """Stellar-mass thresholds for a target galaxy density on the FULL redshift grid.
+
+    The reference's bisection (hmvec/utils.py:9-42, called at hmvec/hmvec.py:426-433) stops only
+    when EVERY redshift has converged, so its result depends on the whole z vector: a slab model
+    that bisects only its own redshifts gets slightly different thresholds (dP_gg ~ 5e-5,
+    SURVEY 8e).  Every rank therefore runs the (tiny: (nz, nm) per iteration) bisection for the
+    full grid redundantly and then passes ``mthresh=result[lo:hi]`` to ``add_hod`` of its slab.
+    Returns mthresh with shape (nz_full,).
+    """
+    from .halomodel import HaloModel
+    full = HaloModel(np.asarray(zs_full, dtype=np.float64), ks, ms=ms, skip_nfw=True, **model_kwargs)
+    pparams = {k: full.p[k] for k in HaloModel._HOD_PARAMS}
+    log10mthresh = full._bisect_mthresh(np.asarray(ngal_full, dtype=np.float64), pparams)
+    return 10 ** (log10mthresh * pparams["hod_A_log10mthresh"])

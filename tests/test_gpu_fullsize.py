@@ -102,3 +102,24 @@ def test_against_oracle_subsample(full):
     for a, b in PAIRS:
         ok, w = power_close(full.get_power(a, b)[sel], o.get_power(a, b))
         assert ok, (a, b, w)
+
+
+def test_ngal_mode_on_a_zslab_uses_the_global_bisection(capsys):
+    """SURVEY 8e exception: add_hod(ngal=...) on a slab must use thresholds bisected on the
+    FULL z grid (the reference's stop test is global over z)."""
+    import hmvec_amd as hm
+    from hmvec_amd.dist import mthresh_from_ngal_global
+    zs = np.linspace(0.05, 2.5, 8)
+    ms = np.geomspace(1e11, 1e16, 40)
+    ks = np.geomspace(1e-3, 10, 16)
+    kw = dict(accuracy="low", engine="analytic")
+    full = hm.HaloModel(zs, ks, ms=ms, **kw)
+    full.add_hod("g0", mthresh=10 ** 10.5 + zs * 0.0)
+    target = full.hods["g0"]["ngal"] * 1.37
+    full.add_hod("g", ngal=target)
+    mthr = mthresh_from_ngal_global(zs, ks, ms, target, **kw)
+    assert np.array_equal(np.log10(mthr), full.hods["g"]["log10mthresh"][:, 0])
+    lo, hi = 2, 4
+    slab = hm.HaloModel(zs[lo:hi], ks, ms=ms, **kw)
+    slab.add_hod("g", mthresh=mthr[lo:hi])
+    assert np.array_equal(slab.get_power("g"), full.get_power("g")[lo:hi])
