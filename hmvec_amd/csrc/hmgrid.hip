@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void integrand_kernel(
     int nxs, int row0, const double* __restrict__ xs, const double* __restrict__ amp,
     const double* __restrict__ xcs, const double* __restrict__ alphas,
     const double* __restrict__ expos, double amp_c, double xc_c, double alpha_c, double expo_c,
-    double gamma, const double* __restrict__ cmax, int do_norm, double* __restrict__ fin,
+    double gamma, const double* __restrict__ cmax, int do_norm, int allow_vec, double* __restrict__ fin,
     double* __restrict__ mnorm) {
     __shared__ double lds[16];
     const int lrow = blockIdx.x, row = row0 + lrow;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void integrand_kernel(
     const double cm = cmax[row];
     double* dst = fin + (size_t)lrow * nxs;
     double acc = 0.0;
-    const bool vec = ((nxs & 1) == 0);  // rows stay 16 B aligned when nxs is even
+    const bool vec = allow_vec && ((nxs & 1) == 0);  // rows stay 16 B aligned when nxs is even
     const int npair = vec ? nxs / 2 : 0;
     for (int p = threadIdx.x; p < npair; p += blockDim.x) {
         const int j = 2 * p;
@@ -1747,7 +1747,8 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
     const int nh = nxs / 2;  // rfft output length is nh+1
     const int rows = nz * nm;
     REQUIRE(step > 0.0, "step must be positive");
-    if (c->use_fused_fft) {
+    const bool xs_aligned = ((uintptr_t)xs % 16) == 0;   // the row kernels read x in 16-B pairs
+    if (c->use_fused_fft && xs_aligned) {
         FusedPlan* FP = nullptr;
         if (get_fused_plan(c, nxs, &FP)) return 1;
         if (FP) {
@@ -1789,7 +1790,7 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
     for (int r0 = 0; r0 < rows; r0 += chunk) {
         const int nr = rows - r0 < chunk ? rows - r0 : chunk;
         hipLaunchKernelGGL(integrand_kernel, dim3(nr), dim3(256), 0, c->stream, nxs, r0, xs, amp, xcs,
-                           alpha, expo, amp_c, xc_c, alpha_c, expo_c, gamma, cmax, do_mass_norm, fin, mnorm);
+                           alpha, expo, amp_c, xc_c, alpha_c, expo_c, gamma, cmax, do_mass_norm, (int)xs_aligned, fin, mnorm);
         HIP_TRY(hipGetLastError());
         FftPlan* P = nullptr;
         if (get_plan(c, nxs, nr, &P)) return 1;
