@@ -119,3 +119,32 @@ def test_spectrum_cache_is_invalidated_by_state_changes():
     g1 = h.get_power_1halo("g")
     h.add_hod("g", mthresh=10 ** 11.5 + zs * 0.0, ignore_existing=True)
     assert not np.allclose(h.get_power_1halo("g"), g1)
+
+
+def test_free_rider_batching_matches_single_pair_kernel():
+    """A get_power_* call computes, in the same pass, every other pair whose tensors are already
+    being streamed; all of them must agree with the single-pair kernel, including for two
+    different HOD names (kept on the per-pair path) and the (b, a) ordering."""
+    import hmvec_amd as hm
+    zs = np.array([0.3, 0.9, 1.6])
+    ms = np.geomspace(1e11, 1e16, 24)
+    ks = np.geomspace(1e-3, 20, 40)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", nxs=300, xmax=20)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    h.add_hod("g2", mthresh=10 ** 11.0 + zs * 0.0, corr="min")
+    names = ["nfw", "electron", "g", "g2"]
+    ref = {}
+    for a in names:
+        for b in names:
+            d1, d2 = h.power_device(a, b)            # single-pair kernel, no cache
+            ref[(a, b)] = (d1.numpy(), d2.numpy())
+    v = h._version
+    p = h.get_power_1halo("nfw")                      # streams only the nfw tensor ...
+    assert ("g", "nfw") in h._pcache and ("g", "g") in h._pcache      # ... g rides along for free
+    assert ("electron", "electron") not in h._pcache                   # a second tensor does not
+    for a in names:
+        for b in names:
+            assert np.allclose(h.get_power_1halo(a, b), ref[(a, b)][0], rtol=1e-12, atol=0), (a, b)
+            assert np.allclose(h.get_power_2halo(a, b), ref[(a, b)][1], rtol=1e-12, atol=0), (a, b)
+    assert h._version == v and np.array_equal(p, h.get_power_1halo("nfw"))
