@@ -43,7 +43,7 @@ class Cosmology(object):
             raise NotImplementedError("CLASS engine is outside the MI355X hot-path scope")
         self.accuracy = accuracy
         self.engine = engine
-        if self.accuracy == "low" and (("S8" in params.keys()) or ("sigma8" in params.keys())):
+        if self.accuracy == "low" and params is not None and (("S8" in params.keys()) or ("sigma8" in params.keys())):
             raise ValueError("Can't use S8 or sigma8 with low accuracy.")
         self.p = dict(params) if params is not None else {}
         for key, val in default_params.items():

@@ -148,3 +148,46 @@ def test_free_rider_batching_matches_single_pair_kernel():
             assert np.allclose(h.get_power_1halo(a, b), ref[(a, b)][0], rtol=1e-12, atol=0), (a, b)
             assert np.allclose(h.get_power_2halo(a, b), ref[(a, b)][1], rtol=1e-12, atol=0), (a, b)
     assert h._version == v and np.array_equal(p, h.get_power_1halo("nfw"))
+
+
+def test_ksz_consumer_call_sequence():
+    """Row N4: the call sequence of the largest in-repo consumer of the path, kSZ.__init__
+    (hmvec/ksz.py:123-141,161-162,196-197): ctor with params=None, add_battaglia_profile by
+    keyword with nxs/xmax=None defaults, add_hod by number density (global bisection), and
+    get_power with name2=/verbose=/b1=/b2= keywords; checked against the oracle."""
+    import hmvec_amd as hm
+    from hmvec_amd.params import battaglia_defaults
+    from oracle import hmref
+    zs = np.array([0.4, 0.8, 1.3])
+    ms = np.geomspace(1e11, 1e16, 40)
+    ks = np.geomspace(0.1, 10.0, 31)
+    ngals = np.array([3e-3, 2e-3, 1e-3])
+    h = hm.HaloModel(zs, ks, ms=ms, params=None, mass_function="sheth-torman", halofit=None, mdef="vir",
+                     nfw_numeric=False, skip_nfw=False, accuracy="low", engine="analytic")
+    h.add_battaglia_profile(name="e", family="AGN", param_override=None, nxs=None, xmax=None,
+                            ignore_existing=False)
+    h.add_hod("g", mthresh=None, ngal=ngals, corr="max", satellite_profile_name="nfw",
+              central_profile_name=None, ignore_existing=False, param_override=None)
+    b1 = np.array([1.2, 1.5, 1.9])
+    sPgg = h.get_power("g", name2="g", verbose=False, b1=b1, b2=b1)
+    sPge = h.get_power("g", name2="e", verbose=False, b1=b1)
+    aPgg = h.get_power("g", "g", verbose=False)
+    aPge = h.get_power("g", "e", verbose=False)
+    bg = np.array([h.hods["g"]["bg"][i] for i in range(zs.size)])
+
+    p = merged_params()
+    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+    ci = hmref.CosmoInputs(h=h.h, omm0=h.omm0, ombh2=p["ombh2"], rho_crit_0=float(h.rho_critical_z(0.0)),
+                           rho_crit_zs=h.rho_critical_z(zs), Pzk=h.Pzk, sPzk=h.sPzk, ks_sigma2=ksig,
+                           h_of_z_zs=h.h_of_z(zs))
+    o = hmref.RefHaloModel(ci, zs, ks, ms, p)
+    o.add_battaglia_profile("e", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"],
+                            p["electron_density_profile_integral_numxs"],
+                            p["electron_density_profile_integral_xmax"])
+    o.add_hod("g", ngal=ngals)
+    assert np.allclose(h.hods["g"]["log10mthresh"], o.hods["g"]["log10mthresh"], rtol=1e-13)
+    assert np.allclose(bg, o.hods["g"]["bg"], rtol=1e-9)
+    for got, (a, b, kw) in ((sPgg, ("g", "g", dict(b1=b1, b2=b1))), (sPge, ("g", "e", dict(b1=b1))),
+                            (aPgg, ("g", "g", {})), (aPge, ("g", "e", {}))):
+        ok, w = power_close(got, o.get_power(a, b, **kw))
+        assert ok, (a, b, kw.keys(), w)
