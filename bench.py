@@ -197,6 +197,29 @@ def main():
         alg["power"] = float(sum(power_alg_bytes(nzl, nm_, nk_, d) for d in PAIR_TENSORS))
     gbs = {k: (alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else None) for k in alg}
 
+    # host <-> device transfer cost if the boundary handed over host buffers (never part of `value`)
+    pcie = None
+    if rank == 0 and world == 1:
+        res_host = [np.empty(a.shape) for a in spec.full]        # caller-provided host buffers
+        for r in res_host:
+            r[...] = 0.0                                           # touch the pages once
+        t1 = time.perf_counter()
+        for _ in range(5):
+            for a, r in zip(spec.full, res_host):
+                nat.check(ctx.lib.hmg_memcpy_d2h(ctx.handle, r.ctypes.data, a.ptr, r.nbytes))
+        d2h_ms = (time.perf_counter() - t1) / 5 * 1e3
+        ins = [h.Pzk, h.sPzk, zs, ms, ks]
+        t1 = time.perf_counter()
+        for _ in range(5):
+            keep = [ctx.upload(a) for a in ins]
+        ctx.sync()
+        h2d_ms = (time.perf_counter() - t1) / 5 * 1e3
+        pcie = {"d2h_results_ms": d2h_ms, "h2d_inputs_ms": h2d_ms,
+                "results_MB": sum(a.nbytes for a in res_host) / 1e6, "inputs_MB": sum(a.nbytes for a in ins) / 1e6,
+                "ms_per_step_incl_transfers": dt_max / K * 1e3 + d2h_ms + h2d_ms,
+                "note": "pageable (pre-touched) numpy buffers, one synchronous copy per array"}
+        del keep
+
     limber = None
     if args.limber and rank == 0:
         full = hm.Cosmology(dict(h.p), accuracy="low", engine="analytic")
@@ -248,6 +271,8 @@ def main():
                                            "(2*FETCH+WRITE)*1024 bytes per launch)" if traffic else None,
                          "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"]},
         }
+        if pcie is not None:
+            out["pcie"] = pcie
         if limber is not None:
             out["limber"] = limber
         if args.detail:
