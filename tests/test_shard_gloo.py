@@ -47,3 +47,44 @@ def test_two_rank_zslab_gather_matches_full_grid(tmp_path):
             # the secant mass conversion is allowed its documented <=7e-15
             assert got[k].shape == full[k].shape
             assert np.allclose(got[k], full[k], rtol=1e-12, atol=0), k
+
+
+def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
+    """The 128-byte RCCL id travels from rank 0 to the other ranks through a file named after
+    the launch (MASTER_PORT, run id, world size, launcher pid); stale files are ignored."""
+    import ctypes
+    import threading
+    import time
+    from hmvec_amd import _native as nat
+    from hmvec_amd import dist
+
+    monkeypatch.setenv("HMG_RDZV_DIR", str(tmp_path))
+
+    class StubLib:
+        @staticmethod
+        def hmg_comm_unique_id(buf):
+            ctypes.memmove(buf, bytes(range(128)), 128)
+            return 0
+
+    class StubCtx:
+        lib = StubLib()
+
+    tag = "29500_none"
+    path = dist.rendezvous_path(tag, 2)
+    # a leftover from a crashed launch long ago must not be picked up
+    with open(path, "wb") as f:
+        f.write(b"\xff" * nat.COMM_ID_BYTES)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    got = {}
+
+    def reader():
+        got["id"] = dist.exchange_unique_id(StubCtx(), 1, 2, tag).raw
+
+    t = threading.Thread(target=reader)
+    t.start()
+    time.sleep(0.2)
+    assert "id" not in got                       # still waiting: the stale file was rejected
+    uid = dist.exchange_unique_id(StubCtx(), 0, 2, tag)
+    t.join(timeout=10)
+    assert got["id"] == uid.raw == bytes(range(128))
