@@ -11,7 +11,7 @@ from conftest import load_golden, merged_params, power_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
-REL = 1e-10
+REL = 1e-12          # gate is 1e-10; measured 1.5e-15 .. 1e-13, see tools/parity_report.py
 UK_ABS = 1e-12
 
 
@@ -55,7 +55,7 @@ def test_inputs_identical(case):
 def test_mass_function(case):
     g, h = case
     assert rel_err(h.sigma2, g["sigma2"]) < REL
-    assert rel_err(h.nzm, g["nzm"]) < 1e-9      # gradient of ln sigma amplifies sigma2's 1e-10
+    assert rel_err(h.nzm, g["nzm"]) < 1e-11     # the gradient of ln sigma amplifies sigma2's rounding ~100x
     assert rel_err(h.bh, g["bh"]) < REL
     assert rel_err(h.concentration(), g["cs"]) < 1e-13
     assert rel_err(h._d_rvir.numpy(), g["rvir"]) < 1e-13
@@ -90,7 +90,7 @@ def test_hod(case):
     g, h = case
     hod = h.hods["g"]
     for k in ("Nc", "Ns", "NsNsm1", "NcNs", "ngal", "bg"):
-        assert np.allclose(hod[k], g["hod_" + k], rtol=1e-9, atol=1e-290), k
+        assert np.allclose(hod[k], g["hod_" + k], rtol=1e-11, atol=1e-290), k
     assert np.allclose(hod["log10mthresh"], g["hod_log10mthresh"], rtol=1e-13)
     assert hod["satellite_profile"] == "nfw"
 
@@ -153,8 +153,8 @@ def test_readme_config1_anchor():
     assert rel_err(h.bh[zi, mi], g["bh"]) < REL
     assert np.max(np.abs(h.uk_profiles["nfw"][zi, mi, ki] - g["uk_nfw"])) < UK_ABS
     assert np.max(np.abs(h.uk_profiles["electron"][zi, mi, ki] - g["uk_electron"])) < UK_ABS
-    assert np.allclose(h.hods["g"]["ngal"], g["hod_ngal"], rtol=1e-9)
-    assert np.allclose(h.hods["g"]["bg"], g["hod_bg"], rtol=1e-9)
+    assert np.allclose(h.hods["g"]["ngal"], g["hod_ngal"], rtol=1e-11)
+    assert np.allclose(h.hods["g"]["bg"], g["hod_bg"], rtol=1e-11)
     names = ["nfw", "electron", "g"]
     for i, a in enumerate(names):
         for b in names[i:]:
