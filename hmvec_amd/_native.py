@@ -70,6 +70,8 @@ SIGNATURES = {
     "hmg_nfw_analytic": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
     "hmg_profile_rowparams": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, C.POINTER(_D * 9), _D, _D, _D,
                               _D, _P, _P, _P, _P, _P, _P, _P],
+    "hmg_profile_rows_from_mvir": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _D, _P, _P, C.POINTER(_D * 9), _D, _D,
+                                   _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hmg_profile_fft": [_P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D, _D,
                         _P, _P, _P, _P, _I, _P, _P],
     "hmg_hod": [_P, _I, _I, C.POINTER(HodParams), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -369,6 +369,31 @@ __global__ void halo_structure_kernel(int nz, int nm, const double* __restrict__
 // ---------------------------------------------------------------- A7: mass conversion
 __device__ __forceinline__ double fcon(double c) { return log(1.0 + c) - c / (1.0 + c); }
 
+// Root of  g(l) = M1 F(c1) - e^l F(c2(l)),  F = 1/mu(c), mu(c) = ln(1+c) - c/(1+c),
+// c2(l) = c1 (e^l ratio / M1)^(1/3), in l = ln M2.  The reference lets scipy.optimize.newton
+// run a vectorised secant from l0 = ln M1 to |dl| < 1.5e-8 with a global stop test; the root
+// is the same, so it is found here by Newton with the analytic derivative
+//   g'(l) = -e^l/mu + e^l mu'(c2) (c2/3)/mu^2,   mu'(c) = c/(1+c)^2
+// (4-5 iterations to full precision instead of ~8 transcendental-heavy secant steps).
+__device__ __forceinline__ double mdelta_solve(double M1, double c1, double ratio) {
+    const double lnM1 = log(M1), MF1 = M1 / fcon(c1);
+    const double kc = c1 * cbrt(ratio / M1);   // c2 = kc * e^(l/3)
+    double p1 = lnM1;
+    for (int it = 0; it < 40; ++it) {
+        const double e3 = exp(p1 * (1.0 / 3.0));
+        const double el = e3 * e3 * e3;
+        const double c2 = kc * e3;
+        const double opc2 = 1.0 + c2;
+        const double mu = log(opc2) - c2 / opc2;
+        const double g = MF1 - el / mu;
+        const double dg = el / mu * (c2 * c2 / (3.0 * opc2 * opc2 * mu) - 1.0);
+        const double dp = g / dg;
+        p1 -= dp;
+        if (fabs(dp) <= 2.0e-16 * fabs(p1)) break;
+    }
+    return exp(p1);
+}
+
 __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
                               const double* __restrict__ cs, const double* __restrict__ d1,
                               double delta2, const double* __restrict__ rho2,
@@ -376,27 +401,7 @@ __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nz * nm) return;
     const int z = idx / nm, m = idx - z * nm;
-    const double M1 = ms[m], c1 = cs[idx], ratio = d1[z] / (delta2 * rho2[z]);
-    const double lnM1 = log(M1), MF1 = M1 * (1.0 / fcon(c1));
-    auto resid = [&](double lm2) {
-        const double c2 = c1 * pow(exp(lm2 - lnM1) * ratio, 1.0 / 3.0);
-        return MF1 - exp(lm2) * (1.0 / fcon(c2));
-    };
-    // secant from (x0, x0(1+dx)+dx), dx = eps^0.33 — the starting pair scipy.optimize.newton uses
-    const double dx = 6.8232e-06;
-    double p0 = lnM1, p1 = lnM1 * (1.0 + dx) + (lnM1 >= 0.0 ? dx : -dx);
-    double q0 = resid(p0), q1 = resid(p1);
-    for (int it = 0; it < 60; ++it) {
-        if (q1 == q0) break;
-        const double dp = q1 * (p1 - p0) / (q1 - q0);
-        const double pn = p1 - dp;
-        p0 = p1;
-        q0 = q1;
-        p1 = pn;
-        if (fabs(dp) <= 4.0e-16 * fabs(pn)) break;
-        q1 = resid(p1);
-    }
-    const double M2 = exp(p1);
+    const double M2 = mdelta_solve(ms[m], cs[idx], d1[z] / (delta2 * rho2[z]));
     m2[idx] = M2;
     r2[idx] = pow(3.0 * M2 / 4.0 / M_PI / delta2 / rho2[z], 1.0 / 3.0);
 }
@@ -501,43 +506,68 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
 
 // ---------------------------------------------------------------- A8/X1: row parameters
 struct RowFit { double f[9]; };
+struct RowOut {
+    double *amp, *xc, *alpha, *expo, *cmax, *rscale, *post;
+};
+__device__ __forceinline__ void rowparams_body(int kind, int idx, double M, double R, double rv, double z1,
+                                               double rhoc, double hz, const RowFit& F, double gamma,
+                                               double alpha_const, double pref, double post_pref,
+                                               const RowOut& O) {
+    const double mr = M / 1.0e14;
+    const double X0 = F.f[0] * pow(mr, F.f[1]) * pow(z1, F.f[2]);
+    const double X1 = F.f[3] * pow(mr, F.f[4]) * pow(z1, F.f[5]);
+    const double X2 = F.f[6] * pow(mr, F.f[7]) * pow(z1, F.f[8]);
+    if (kind == HMG_PROF_BATTAGLIA_GAS) {
+        // (Ob/Om) rho_c rho0 x^g (1+x^alpha)^(-(beta+g)/alpha),  x = r/(R200c/2)
+        O.amp[idx] = pref * rhoc * X0;
+        O.xc[idx] = 1.0;
+        O.alpha[idx] = X1;
+        O.expo[idx] = (X2 + gamma) / X1;
+        const double rg = R / 2.0;
+        O.rscale[idx] = rg;
+        O.cmax[idx] = rv / rg;
+        if (O.post) O.post[idx] = 1.0;
+    } else {
+        // eFrac (Ob/Om) 200 M G rho_c / (2 R200) P0 (x/xc)^g (1+(x/xc)^alpha)^(-beta),  x = r/R200c
+        O.amp[idx] = pref * M * rhoc / (2.0 * R) * X0;
+        O.xc[idx] = X1;
+        O.alpha[idx] = alpha_const;
+        O.expo[idx] = X2;
+        O.rscale[idx] = R;
+        O.cmax[idx] = rv / R;
+        if (O.post) O.post[idx] = post_pref * ((R * R * R) * ((z1 * z1) / hz));
+    }
+}
+
 __global__ void rowparams_kernel(int kind, int nz, int nm, const double* __restrict__ m200,
                                  const double* __restrict__ r200, const double* __restrict__ rvir,
                                  const double* __restrict__ zs, const double* __restrict__ rhoc,
                                  const double* __restrict__ hz, RowFit F, double gamma,
-                                 double alpha_const, double pref, double post_pref,
-                                 double* __restrict__ amp, double* __restrict__ xc,
-                                 double* __restrict__ alpha, double* __restrict__ expo,
-                                 double* __restrict__ cmax, double* __restrict__ rscale,
-                                 double* __restrict__ post) {
+                                 double alpha_const, double pref, double post_pref, RowOut O) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nz * nm) return;
     const int z = idx / nm;
-    const double M = m200[idx], mr = M / 1.0e14, z1 = 1.0 + zs[z];
-    const double X0 = F.f[0] * pow(mr, F.f[1]) * pow(z1, F.f[2]);
-    const double X1 = F.f[3] * pow(mr, F.f[4]) * pow(z1, F.f[5]);
-    const double X2 = F.f[6] * pow(mr, F.f[7]) * pow(z1, F.f[8]);
-    const double R = r200[idx];
-    if (kind == HMG_PROF_BATTAGLIA_GAS) {
-        // (Ob/Om) rho_c rho0 x^g (1+x^alpha)^(-(beta+g)/alpha),  x = r/(R200c/2)
-        amp[idx] = pref * rhoc[z] * X0;
-        xc[idx] = 1.0;
-        alpha[idx] = X1;
-        expo[idx] = (X2 + gamma) / X1;
-        const double rg = R / 2.0;
-        rscale[idx] = rg;
-        cmax[idx] = rvir[idx] / rg;
-        if (post) post[idx] = 1.0;
-    } else {
-        // eFrac (Ob/Om) 200 M G rho_c / (2 R200) P0 (x/xc)^g (1+(x/xc)^alpha)^(-beta),  x = r/R200c
-        amp[idx] = pref * M * rhoc[z] / (2.0 * R) * X0;
-        xc[idx] = X1;
-        alpha[idx] = alpha_const;
-        expo[idx] = X2;
-        rscale[idx] = R;
-        cmax[idx] = rvir[idx] / R;
-        if (post) post[idx] = post_pref * ((R * R * R) * ((z1 * z1) / hz[z]));
-    }
+    rowparams_body(kind, idx, m200[idx], r200[idx], rvir[idx], 1.0 + zs[z], rhoc[z], hz ? hz[z] : 1.0, F,
+                   gamma, alpha_const, pref, post_pref, O);
+}
+
+// mass conversion + row parameters in one launch (one kernel boundary fewer per profile)
+__global__ void rows_from_mvir_kernel(int kind, int nz, int nm, const double* __restrict__ ms,
+                                      const double* __restrict__ cs, const double* __restrict__ rvir,
+                                      const double* __restrict__ zs, const double* __restrict__ d1,
+                                      double delta2, const double* __restrict__ rhoc,
+                                      const double* __restrict__ hz, RowFit F, double gamma,
+                                      double alpha_const, double pref, double post_pref,
+                                      double* __restrict__ m2, double* __restrict__ r2, RowOut O) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nz * nm) return;
+    const int z = idx / nm, m = idx - z * nm;
+    const double M2 = mdelta_solve(ms[m], cs[idx], d1[z] / (delta2 * rhoc[z]));
+    const double R2 = pow(3.0 * M2 / 4.0 / M_PI / delta2 / rhoc[z], 1.0 / 3.0);
+    m2[idx] = M2;
+    r2[idx] = R2;
+    rowparams_body(kind, idx, M2, R2, rvir[idx], 1.0 + zs[z], rhoc[z], hz ? hz[z] : 1.0, F, gamma,
+                   alpha_const, pref, post_pref, O);
 }
 
 // ---------------------------------------------------------------- K4: profile integrand (F1)
@@ -1708,9 +1738,30 @@ int hmg_profile_rowparams(hmg_ctx* c, int kind, int nz, int nm, const double* m2
     REQUIRE(nz > 0 && nm > 0, "empty grid");
     RowFit F;
     for (int i = 0; i < 9; ++i) F.f[i] = f[i];
-    hipLaunchKernelGGL(rowparams_kernel, grid1d((size_t)nz * nm, 256), dim3(256), 0, c->stream, kind,
-                       nz, nm, m200, r200, rvir, zs, rhoc, hz, F, gamma, alpha_const, pref, post_pref,
-                       amp, xc, alpha, expo, cmax, rscale, post);
+    RowOut O{amp, xc, alpha, expo, cmax, rscale, post};
+    hipLaunchKernelGGL(rowparams_kernel, grid1d((size_t)nz * nm, 128), dim3(128), 0, c->stream, kind,
+                       nz, nm, m200, r200, rvir, zs, rhoc, hz, F, gamma, alpha_const, pref, post_pref, O);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_profile_rows_from_mvir(hmg_ctx* c, int kind, int nz, int nm, const double* ms, const double* cs,
+                               const double* rvir, const double* zs, const double* drho1, double delta2,
+                               const double* rhoc, const double* hz, const double f[9], double gamma,
+                               double alpha_const, double pref, double post_pref, double* m200,
+                               double* r200, double* amp, double* xc, double* alpha, double* expo,
+                               double* cmax, double* rscale, double* post) {
+    REQUIRE(c && ms && cs && rvir && zs && drho1 && rhoc && f && m200 && r200 && amp && xc && alpha && expo &&
+                cmax && rscale, "NULL argument");
+    REQUIRE(kind == HMG_PROF_BATTAGLIA_GAS || kind == HMG_PROF_BATTAGLIA_PRES, "unknown profile kind");
+    REQUIRE(kind != HMG_PROF_BATTAGLIA_PRES || (hz && post), "pressure needs d_hz and d_post");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    RowFit F;
+    for (int i = 0; i < 9; ++i) F.f[i] = f[i];
+    RowOut O{amp, xc, alpha, expo, cmax, rscale, post};
+    hipLaunchKernelGGL(rows_from_mvir_kernel, grid1d((size_t)nz * nm, 128), dim3(128), 0, c->stream, kind,
+                       nz, nm, ms, cs, rvir, zs, drho1, delta2, rhoc, hz, F, gamma, alpha_const, pref,
+                       post_pref, m200, r200, O);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -378,15 +378,19 @@ class HaloModel(Cosmology):
         if not getattr(self, "_m200c_valid", False):
             if self._use_lanes and self._EV_HALO in self._recorded:
                 ctx.wait(self._EV_HALO)       # c(z,m) is produced on lane 1
-            def drho1():
-                delta, rho = self._mdef_delta_rho()
-                return rho * delta if self.mdef == "vir" else rho * 200.0
-            d1 = self._dev("drho1", drho1)
+            d1 = self._d_drho1()
             d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
             ctx.call("hmg_mdelta_convert", nz, nm, self._d_ms().ptr, self._d_cs.ptr, d1.ptr, 200.0,
                      d_rhoc.ptr, m2.ptr, r2.ptr)
             self._m200c_valid = True
         return m2, r2
+
+    def _d_drho1(self):
+        """Delta * rho(z) of the model's own mass definition (hmvec/hmvec.py:217-220)."""
+        def drho1():
+            delta, rho = self._mdef_delta_rho()
+            return rho * delta if self.mdef == "vir" else rho * 200.0
+        return self._dev("drho1", drho1)
 
     def _fft_grids(self, xmax, nxs):
         """x grid and FFT wavenumber grid exactly as hmvec/fft.py:45-50,73 build them."""
@@ -415,11 +419,22 @@ class HaloModel(Cosmology):
     def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref):
         ctx = self._ctx()
         nz, nm = self._nz, self._nm
-        m200c, r200c = self._m200c()
         outs = [self._buf((key, "rowp", i), (nz, nm)) for i in range(7)]
         fit = (C.c_double * 9)(*fit9)
         d_hz = self._dev("hz", lambda: self.h_of_z(self.zs))
         d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
+        if not getattr(self, "_m200c_valid", False):
+            # mass conversion and row parameters in one launch
+            if self._use_lanes and self._EV_HALO in self._recorded:
+                ctx.wait(self._EV_HALO)
+            m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
+            ctx.call("hmg_profile_rows_from_mvir", kind, nz, nm, self._d_ms().ptr, self._d_cs.ptr,
+                     self._d_rvir.ptr, self._d_zs().ptr, self._d_drho1().ptr, 200.0, d_rhoc.ptr, d_hz.ptr,
+                     C.byref(fit), float(gamma), float(alpha_const), float(pref), float(post_pref),
+                     m2.ptr, r2.ptr, *[o.ptr for o in outs])
+            self._m200c_valid = True
+            return outs
+        m200c, r200c = self._m200c()
         ctx.call("hmg_profile_rowparams", kind, nz, nm, m200c.ptr, r200c.ptr, self._d_rvir.ptr,
                  self._d_zs().ptr, d_rhoc.ptr, d_hz.ptr, C.byref(fit), float(gamma), float(alpha_const),
                  float(pref), float(post_pref), *[o.ptr for o in outs])

@@ -142,6 +142,18 @@ int hmg_profile_rowparams(hmg_ctx* ctx, int kind, int nz, int nm, const double* 
                           double* d_cmax /* rvir/rscale */, double* d_rscale /* R200c/2 (gas) or R200c (pressure) */,
                           double* d_post /* pressure: post_prefactor R200c^3 (1+z)^2/H(z); gas: may be NULL */);
 
+/* hmg_mdelta_convert (with drho2 = delta2 * rhocz) + hmg_profile_rowparams in one launch; also
+ * writes d_m200c / d_r200c.  Same results; one kernel boundary fewer per profile.           */
+int hmg_profile_rows_from_mvir(hmg_ctx* ctx, int kind, int nz, int nm, const double* d_ms,
+                               const double* d_cs, const double* d_rvir, const double* d_zs,
+                               const double* d_drho1 /*[nz]*/, double delta2,
+                               const double* d_rhocz /*[nz]*/, const double* d_hz /*[nz] or NULL*/,
+                               const double h_fit[9], double gamma, double alpha_const,
+                               double amp_prefactor, double post_prefactor,
+                               double* d_m200c, double* d_r200c,
+                               double* d_amp, double* d_xc, double* d_alpha, double* d_expo,
+                               double* d_cmax, double* d_rscale, double* d_post);
+
 /* ---- F1-F3: radial-profile sine transform + per-(z,m) k-interpolation ------------------
  * Replaces generic_profile_fft / fft_integral / _interp_loop (hmvec/fft.py:35-115),
  * bug-compatibly (step=(x[-1]-x[0])/N, 0-based DFT phase, left=u[first k>0], right=0,
