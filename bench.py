@@ -160,6 +160,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(K):
         step(16 + s * SLOTS_PER_STEP)
+    t_issue = time.perf_counter() - t0        # host time to enqueue K steps (launches are asynchronous)
     comm.barrier()
     ctx.sync()
     dt = time.perf_counter() - t0
@@ -256,6 +257,7 @@ def main():
             "metric": "(z,m,k) grid-points/sec for P_1h+P_2h",
             "value": pts * K / dt_max, "unit": "grid-points/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
+            "host_issue_ms_per_step": t_issue / K * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Config 3: zs={zs.size} ms={ms.size} ks={ks.size}, analytic NFW + "

@@ -8,8 +8,11 @@ first kernel call does (and fails loudly if it is not built).
 """
 from .params import battaglia_defaults, default_params  # noqa: F401
 from .cosmology import Cosmology  # noqa: F401
-from .halomodel import HaloModel, R_from_M, duffy_concentration  # noqa: F401
-from . import cosmology, params, quadrature  # noqa: F401
+from .halomodel import HaloModel  # noqa: F401
+from .functions import *  # noqa: F401,F403  (the reference's free functions, GPU-backed)
+from .fft import generic_profile_fft  # noqa: F401  (hmvec/hmvec.py:3 star-imports it into the package)
+from . import cosmology, fft, functions, params, quadrature, tinker, utils  # noqa: F401
+from .functions import __all__ as _fn_all
 
-__all__ = ["HaloModel", "Cosmology", "default_params", "battaglia_defaults",
-           "duffy_concentration", "R_from_M"]
+__all__ = ["HaloModel", "Cosmology", "default_params", "battaglia_defaults", "generic_profile_fft",
+           "fft", "tinker", "utils", "cosmology", "params"] + list(_fn_all)

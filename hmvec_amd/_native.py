@@ -80,6 +80,11 @@ SIGNATURES = {
     "hmg_power_batch": [_P, _I, _I, _I, _I, C.POINTER(Tracer), _I, C.POINTER(_I), C.POINTER(_I),
                         _P, _P, _P, _P, _P, _P, _D, _D, C.POINTER(_P), C.POINTER(_P)],
     "hmg_limber": [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "hmg_fn2d": [_P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_D), _I, _P],
+    "hmg_mstellar_halo": [_P, _I, _I, _P, _P, _P],
+    "hmg_trapz_rows": [_P, _I, _I, _P, _P, _P],
+    "hmg_sine_transform": [_P, _I, _I, _P, _P, _P],
+    "hmg_profile_fft_table": [_P, _I, _I, _I, _I, _D, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "hmg_comm_unique_id": [C.c_char * COMM_ID_BYTES],
     "hmg_comm_init": [_P, C.c_char * COMM_ID_BYTES, _I, _I],
     "hmg_comm_allgather": [_P, _P, _P, _Z],

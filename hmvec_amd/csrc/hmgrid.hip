@@ -879,6 +879,24 @@ __device__ __forceinline__ double shmr_log10mh(double lms, double a, const ShmrS
 }
 
 constexpr int SHMR_N = 4000;
+// log10 M* grid of the reference's inverse table, np.linspace(-18,18,4000) (hmvec.py:640)
+__device__ __forceinline__ double shmr_grid(int j) {
+    const double gstep = 36.0 / (double)(SHMR_N - 1);
+    return j == SHMR_N - 1 ? 18.0 : (double)j * gstep + (-18.0);
+}
+// np.interp(lmh, mh, grid) with numpy's clamped ends and exact-knot rule (hmvec.py:645)
+__device__ __forceinline__ double shmr_inverse(const double* mh /* LDS, SHMR_N */, double lmh) {
+    if (lmh < mh[0]) return shmr_grid(0);
+    if (lmh >= mh[SHMR_N - 1]) return shmr_grid(SHMR_N - 1);
+    int lo = 0, hi = SHMR_N - 1;          // mh[lo] <= lmh < mh[lo+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (mh[mid] <= lmh) lo = mid; else hi = mid;
+    }
+    if (mh[lo] == lmh) return shmr_grid(lo);
+    const double slope = (shmr_grid(lo + 1) - shmr_grid(lo)) / (mh[lo + 1] - mh[lo]);
+    return slope * (lmh - mh[lo]) + shmr_grid(lo);
+}
 struct HodDev {
     double sig, alphasat, Bsat, betasat, Bcut, betacut;
     int corr;
@@ -901,9 +919,7 @@ __global__ __launch_bounds__(1024) void hod_kernel(int nm, HodDev P, const doubl
     const int z = blockIdx.x;
     const double zz = zs[z], a = 1.0 / (1.0 + zz);
     const ShmrSet S = shmr_for(zz);
-    const double gstep = 36.0 / (double)(SHMR_N - 1);  // np.linspace(-18,18,4000)
-    auto grid = [&](int j) { return j == SHMR_N - 1 ? 18.0 : (double)j * gstep + (-18.0); };
-    for (int j = threadIdx.x; j < SHMR_N; j += blockDim.x) mh[j] = shmr_log10mh(grid(j), a, S);
+    for (int j = threadIdx.x; j < SHMR_N; j += blockDim.x) mh[j] = shmr_log10mh(shmr_grid(j), a, S);
     __syncthreads();
     const double thr = lthr[z];
     const double mthr_halo = shmr_log10mh(thr, a, S);
@@ -913,25 +929,7 @@ __global__ __launch_bounds__(1024) void hod_kernel(int nm, HodDev P, const doubl
     double acc_n = 0.0, acc_b = 0.0;
     for (int m = threadIdx.x; m < nm; m += blockDim.x) {
         const double lmh = log10(ms[m]);
-        // np.interp(lmh, mh, grid): binary search for mh[j] <= lmh < mh[j+1]
-        double lmstar;
-        if (lmh < mh[0]) {
-            lmstar = grid(0);
-        } else if (lmh >= mh[SHMR_N - 1]) {
-            lmstar = grid(SHMR_N - 1);
-        } else {
-            int lo = 0, hi = SHMR_N - 1;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (mh[mid] <= lmh) lo = mid; else hi = mid;
-            }
-            if (mh[lo] == lmh) {
-                lmstar = grid(lo);
-            } else {
-                const double slope = (grid(lo + 1) - grid(lo)) / (mh[lo + 1] - mh[lo]);
-                lmstar = slope * (lmh - mh[lo]) + grid(lo);
-            }
-        }
+        const double lmstar = shmr_inverse(mh, lmh);
         const double nc = 0.5 * (1.0 - erf((thr - lmstar) / denom));
         const double mass = pow10_fast(lmh);
         const double ns = nc * powr_fast(mass / Msat, P.alphasat) * exp(-Mcut / mass);
@@ -1413,6 +1411,223 @@ __global__ void limber_kernel(int nells, const double* __restrict__ ells, int nz
         acc += wz[g] * (val * pref[g]);
     }
     out[e] = acc;
+}
+
+// ---------------------------------------------------------------- function mirrors (hmg_fn2d & co)
+// The reference's free functions on the path, evaluated over a broadcast (rows, cols) grid.
+// These mirror numpy's expressions operation by operation (generic pow/exp/log10, no fused
+// multiply-add) - they are the API-parity entry points, not the fused hot kernels above.
+struct FnArgs {
+    int op, rows, cols;
+    const double* in[HMG_FN_MAXIN];
+    int sr[HMG_FN_MAXIN], sc[HMG_FN_MAXIN];
+    double par[HMG_FN_MAXPAR];
+    double* out;
+};
+
+__device__ __forceinline__ double batt_fit(double m, double z, const double* f) {
+    return f[0] * pow(m / 1.0e14, f[1]) * pow(1.0 + z, f[2]);
+}
+
+__global__ __launch_bounds__(256) void fn2d_kernel(FnArgs A) {
+#pragma clang fp contract(off)
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)A.rows * A.cols) return;
+    const int r = (int)(idx / A.cols), c = (int)(idx - (size_t)r * A.cols);
+    auto X = [&](int i) { return A.in[i][(size_t)r * A.sr[i] + (size_t)c * A.sc[i]]; };
+    const double* par = A.par;
+    double y = 0.0;
+    switch (A.op) {
+    case HMG_FN_TINKER_BIAS: {
+        const double nu = X(0), dc = 1.686, yy = log10(par[0]);
+        const double ey = exp(-pow(4.0 / yy, 4.0));
+        const double Ay = 1.0 + 0.24 * yy * ey, ay = 0.44 * yy - 0.88, Cy = 0.019 + 0.107 * yy + 0.19 * ey;
+        const double nua = pow(nu, ay);
+        y = 1.0 - Ay * (nua / (nua + pow(dc, ay))) + 0.183 * pow(nu, 1.5) + Cy * pow(nu, 2.4);
+        break;
+    }
+    case HMG_FN_TINKER_FNU: {
+        const double nu = X(0), zin = X(1);
+        // zs*heaviside(3-zs,0) + 3*heaviside(zs-3,0): z<3 -> z, z==3 -> 0, z>3 -> 3 (tinker.py:53)
+        const double z = zin < 3.0 ? zin : (zin > 3.0 ? 3.0 : 0.0);
+        const double beta = 0.589 * pow(1.0 + z, 0.20), phi = -0.729 * pow(1.0 + z, -0.08);
+        const double eta = -0.243 * pow(1.0 + z, 0.27), gamma = 0.864 * pow(1.0 + z, -0.01);
+        const double un = (1.0 + pow(beta * nu, -2.0 * phi)) * pow(nu, 2.0 * eta) * exp(-gamma * (nu * nu) / 2.0);
+        double alpha = par[1];
+        if (par[0] != 0.0) {   // interp1d(izs, ialphas) - linear; out-of-range z is rejected on the host
+            const double* tz = A.in[2];
+            const double* ta = A.in[3];
+            const int nt = (int)par[2];
+            int lo = 0, hi = nt - 1;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (tz[mid] < z) lo = mid; else hi = mid;     // searchsorted(side='left') bracket
+            }
+            const double slope = (ta[hi] - ta[lo]) / (tz[hi] - tz[lo]);
+            alpha = slope * (z - tz[lo]) + ta[lo];
+        }
+        y = alpha * un;
+        break;
+    }
+    case HMG_FN_MHALO_STELLAR: {
+        const double z = X(0), lms = X(1), a = 1.0 / (1.0 + z), am1 = a - 1.0;
+        const ShmrSet s = shmr_for(z);
+        const double d = lms - (s.Ms0 + s.Msa * am1);
+        y = -0.5 + (s.M1 + s.M1a * am1) + (s.b0 + s.ba * am1) * d +
+            pow(10.0, (s.d0 + s.da * am1) * d) / (1.0 + pow(10.0, -(s.g0 + s.ga * am1) * d));
+        break;
+    }
+    case HMG_FN_HOD_NC:
+        y = 0.5 * (1.0 - erf((X(1) - X(0)) / (sqrt(2.0) * par[0])));
+        break;
+    case HMG_FN_HOD_NS: {
+        const double mass = pow(10.0, X(1));
+        y = X(0) * pow(mass / X(2), par[0]) * exp(-X(3) / mass);
+        break;
+    }
+    case HMG_FN_HOD_MFUNC:
+        y = 1.0e12 * par[0] * pow(10.0, (X(0) - 12.0) * par[1]);
+        break;
+    case HMG_FN_HOD_NSNSM1: {
+        const double nc = X(0), ns = X(1);
+        if (par[0] == 0.0) y = (fabs(nc) <= 1.0e-8) ? 0.0 : (ns * ns) / nc;   // np.isclose(Nc, 0)
+        else y = ns * ns;
+        break;
+    }
+    case HMG_FN_HOD_NCNS:
+        y = par[0] == 0.0 ? X(1) : X(1) * X(0);
+        break;
+    case HMG_FN_FCON: {
+        const double cc = X(0);
+        y = log(1.0 + cc) - cc / (1.0 + cc);
+        break;
+    }
+    case HMG_FN_RHO_NFW: {
+        const double x = X(0) / X(2), op = 1.0 + x;
+        y = X(1) / x / (op * op);
+        break;
+    }
+    case HMG_FN_R_FROM_M:
+        y = pow(3.0 * X(0) / 4.0 / M_PI / X(2) / X(1), 1.0 / 3.0);
+        break;
+    case HMG_FN_DUFFY:
+        y = par[0] * pow(par[3] * X(0) / 2.0e12, par[1]) * pow(1.0 + X(1), par[2]);
+        break;
+    case HMG_FN_BATT_FIT:
+        y = batt_fit(X(0), X(1), par);
+        break;
+    case HMG_FN_RHO_GAS_X:
+    case HMG_FN_RHO_GAS_R: {
+        const double m = X(1), z = X(2), rhoc = X(3);
+        double x = X(0);
+        if (A.op == HMG_FN_RHO_GAS_R) x = 2.0 * x / pow(3.0 * m / 4.0 / M_PI / 200.0 / rhoc, 1.0 / 3.0);
+        const double omb = par[0], omm = par[1], gamma = par[2];
+        const double rho0 = batt_fit(m, z, par + 3), alpha = batt_fit(m, z, par + 6), beta = batt_fit(m, z, par + 9);
+        y = (omb / omm) * rhoc * rho0 * pow(x, gamma) * pow(1.0 + pow(x, alpha), -(beta + gamma) / alpha);
+        break;
+    }
+    case HMG_FN_PE_X:
+    case HMG_FN_PE_R: {
+        double x = X(0), m, R200, z, rhoc;
+        if (A.op == HMG_FN_PE_X) {
+            m = X(1); R200 = X(2); z = X(3); rhoc = X(4);
+        } else {
+            m = X(1); z = X(2); rhoc = X(3);
+            R200 = pow(3.0 * m / 4.0 / M_PI / 200.0 / rhoc, 1.0 / 3.0);
+            x = x / R200;
+        }
+        const double omb = par[0], omm = par[1], alpha = par[2], gamma = par[3], G = par[13];
+        const double P0 = batt_fit(m, z, par + 4), xc = batt_fit(m, z, par + 7), beta = batt_fit(m, z, par + 10);
+        const double eFrac = 2.0 * (0.76 + 1.0) / (5.0 * 0.76 + 3.0);
+        const double t = x / xc;
+        y = eFrac * (omb / omm) * 200.0 * m * G * rhoc / (2.0 * R200) * P0 * pow(t, gamma) *
+            pow(1.0 + pow(t, alpha), -beta);
+        break;
+    }
+    case HMG_FN_NGAL_INTEGRAND:
+        y = X(0) * (X(1) + X(2));
+        break;
+    case HMG_FN_A2Z:
+        y = 1.0 / X(0) - 1.0;
+        break;
+    case HMG_FN_MDELTA:
+        y = mdelta_solve(X(0), X(1), X(2) / X(3));
+        break;
+    case HMG_FN_BG_INTEGRAND:
+        y = X(0) * (X(1) + X(2)) * X(3);
+        break;
+    }
+    A.out[idx] = y;
+}
+
+// Mstellar_halo: one block per z, table in LDS, exactly the inversion hod_kernel uses.
+__global__ __launch_bounds__(1024) void mstellar_halo_kernel(int nm, const double* __restrict__ zs,
+                                                            const double* __restrict__ lmh,
+                                                            double* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ double mh[SHMR_N];
+    const int z = blockIdx.x;
+    const double zz = zs[z], a = 1.0 / (1.0 + zz);
+    const ShmrSet S = shmr_for(zz);
+    for (int j = threadIdx.x; j < SHMR_N; j += blockDim.x) mh[j] = shmr_log10mh(shmr_grid(j), a, S);
+    __syncthreads();
+    for (int m = threadIdx.x; m < nm; m += blockDim.x) out[(size_t)z * nm + m] = shmr_inverse(mh, lmh[m]);
+}
+
+// np.trapz(y, x, axis=-1): sum_i (x[i+1]-x[i]) * (y[i+1]+y[i]) / 2, one block per row.
+__global__ __launch_bounds__(256) void trapz_rows_kernel(int cols, const double* __restrict__ y,
+                                                         const double* __restrict__ x,
+                                                         double* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ double lds[16];
+    const double* row = y + (size_t)blockIdx.x * cols;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i + 1 < cols; i += blockDim.x) acc += (x[i + 1] - x[i]) * (row[i + 1] + row[i]) / 2.0;
+    const double tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+// fft_integral pieces: integrand x*y, and uk = -Im(F) * step
+__global__ void xy_kernel(int rows, int n, const double* __restrict__ x, const double* __restrict__ y,
+                          double* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * n) return;
+    out[idx] = x[idx % n] * y[idx];
+}
+__global__ void neg_imag_kernel(size_t count, double step, const double2* __restrict__ F, double* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    out[idx] = -F[idx].y * step;
+}
+
+// Tabulated-integrand twin of integrand_kernel (generic_profile_fft with an arbitrary rhofunc_x):
+// theta(|x| <= cmax) * rho, the R2C input x*rho*theta and the trapz mass norm of the row.
+__global__ __launch_bounds__(256) void table_integrand_kernel(int nxs, int row0, const double* __restrict__ xs,
+                                                              const double* __restrict__ rho, int rho_shared,
+                                                              const double* __restrict__ cmax, int do_norm,
+                                                              double* __restrict__ fin, double* __restrict__ mnorm) {
+#pragma clang fp contract(off)
+    __shared__ double lds[16];
+    const int lrow = blockIdx.x, row = row0 + lrow;
+    const double* src = rho + (rho_shared ? 0 : (size_t)row * nxs);
+    const double cm = cmax[row];
+    double* dst = fin + (size_t)lrow * nxs;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < nxs; j += blockDim.x) {
+        const double x = xs[j];
+        const double rv = (fabs(x) > cm) ? 0.0 : src[j];
+        dst[j] = x * rv;
+        if (do_norm) {
+            const double xl = (j > 0) ? xs[j - 1] : x, xr = (j + 1 < nxs) ? xs[j + 1] : x;
+            acc += 0.5 * (xr - xl) * (rv * (x * x));
+        }
+    }
+    if (do_norm) {
+        const double tot = block_sum(acc, lds);
+        if (threadIdx.x == 0) mnorm[lrow] = tot;
+    } else if (threadIdx.x == 0) {
+        mnorm[lrow] = 1.0;
+    }
 }
 
 }  // namespace hmg
@@ -2112,6 +2327,130 @@ int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const 
     hipLaunchKernelGGL(limber_kernel, grid1d((size_t)nells, 128), dim3(128), 0, c->stream, nells, ells, nz,
                        nk, zs, ks, P, ngz, gzs, pref, chis, wz, out);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- function mirrors ------------------------------------------------------------------------
+int hmg_fn2d(hmg_ctx* c, int op, int rows, int cols, int nin, const double* const* in, const int* sr,
+             const int* sc, const double* par, int npar, double* out) {
+    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4};
+    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0};
+    REQUIRE(c && in && sr && sc && out, "NULL argument");
+    REQUIRE(op >= 0 && op < HMG_FN_COUNT, "unknown function id");
+    REQUIRE(rows > 0 && cols > 0, "empty grid");
+    REQUIRE(nin == need_in[op] && nin <= HMG_FN_MAXIN, "wrong number of inputs for this function");
+    REQUIRE(npar == need_par[op] && npar <= HMG_FN_MAXPAR && (npar == 0 || par), "wrong number of parameters for this function");
+    FnArgs A;
+    A.op = op; A.rows = rows; A.cols = cols; A.out = out;
+    for (int i = 0; i < HMG_FN_MAXIN; ++i) { A.in[i] = nullptr; A.sr[i] = 0; A.sc[i] = 0; }
+    for (int i = 0; i < nin; ++i) {
+        REQUIRE(in[i], "NULL input");
+        REQUIRE(sr[i] >= 0 && sc[i] >= 0, "negative stride");
+        A.in[i] = in[i]; A.sr[i] = sr[i]; A.sc[i] = sc[i];
+    }
+    for (int i = 0; i < HMG_FN_MAXPAR; ++i) A.par[i] = i < npar ? par[i] : 0.0;
+    if (op == HMG_FN_TINKER_FNU) REQUIRE(par[0] == 0.0 || par[2] >= 2.0, "alpha table needs >= 2 rows");
+    if (op == HMG_FN_HOD_NSNSM1 || op == HMG_FN_HOD_NCNS) REQUIRE(par[0] == 0.0 || par[0] == 1.0, "corr must be 0 (max) or 1 (min)");
+    hipLaunchKernelGGL(fn2d_kernel, grid1d((size_t)rows * cols, 256), dim3(256), 0, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_mstellar_halo(hmg_ctx* c, int nz, int nm, const double* zs, const double* lmh, double* out) {
+    REQUIRE(c && zs && lmh && out, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    hipLaunchKernelGGL(mstellar_halo_kernel, dim3(nz), dim3(1024), 0, c->stream, nm, zs, lmh, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_trapz_rows(hmg_ctx* c, int rows, int cols, const double* y, const double* x, double* out) {
+    REQUIRE(c && y && x && out, "NULL argument");
+    REQUIRE(rows > 0 && cols > 0, "empty grid");
+    hipLaunchKernelGGL(trapz_rows_kernel, dim3(rows), dim3(256), 0, c->stream, cols, y, x, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_sine_transform(hmg_ctx* c, int rows, int n, const double* x, const double* y, double* uk) {
+    REQUIRE(c && x && y && uk, "NULL argument");
+    REQUIRE(rows > 0 && n >= 2, "bad sizes");
+    const int nh1 = n / 2 + 1;
+    // chunk the batch like the profile path so the work buffers stay bounded
+    int chunk = (int)(((size_t)160 << 20) / ((size_t)n * 8 + (size_t)nh1 * 16));
+    if (chunk < 1) chunk = 1;
+    if (chunk > rows) chunk = rows;
+    if (ensure_scratch(c, 0, (size_t)chunk * n * 8)) return 1;
+    if (ensure_scratch(c, 1, (size_t)chunk * nh1 * 16)) return 1;
+    double* fin = (double*)c->scratch[0];
+    double2* fout = (double2*)c->scratch[1];
+    // step = (x[-1]-x[0])/N needs the end points of the device grid
+    double ends[2];
+    HIP_TRY(hipMemcpyAsync(&ends[0], x, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&ends[1], x + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double step = (ends[1] - ends[0]) / (double)n;
+    for (int r0 = 0; r0 < rows; r0 += chunk) {
+        const int nr = rows - r0 < chunk ? rows - r0 : chunk;
+        hipLaunchKernelGGL(xy_kernel, grid1d((size_t)nr * n, 256), dim3(256), 0, c->stream, nr, n, x,
+                           y + (size_t)r0 * n, fin);
+        HIP_TRY(hipGetLastError());
+        FftPlan* P = nullptr;
+        if (get_plan(c, n, nr, &P)) return 1;
+        void* ib[1] = {fin};
+        void* ob[1] = {fout};
+        FFT_TRY(rocfft_execution_info_set_stream(P->info, c->stream));
+        FFT_TRY(rocfft_execute(P->plan, ib, ob, P->info));
+        hipLaunchKernelGGL(neg_imag_kernel, grid1d((size_t)nr * nh1, 256), dim3(256), 0, c->stream,
+                           (size_t)nr * nh1, step, (const double2*)fout, uk + (size_t)r0 * nh1);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int hmg_profile_fft_table(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, const double* xs,
+                          const double* kts, const double* rho, int rho_rows, const double* cmax,
+                          const double* rss, const double* zs, const double* ks, int do_mass_norm,
+                          double* out) {
+    REQUIRE(c && xs && kts && rho && cmax && rss && zs && ks && out, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
+    REQUIRE(nxs >= 4, "nxs too small");
+    REQUIRE(step > 0.0, "step must be positive");
+    const int rows = nz * nm;
+    REQUIRE(rho_rows == 1 || rho_rows == rows, "rho must have 1 or nz*nm rows");
+    const int nh = nxs / 2;
+    const size_t per_row = (size_t)nxs * 8 + (size_t)(nh + 1) * 16;
+    size_t budget = c->fft_chunk_bytes ? c->fft_chunk_bytes : ((size_t)160 << 20);
+    int chunk = (int)(budget / per_row);
+    if (chunk < 1) chunk = 1;
+    if (chunk > rows) chunk = rows;
+    if (ensure_scratch(c, 0, (size_t)chunk * nxs * 8)) return 1;
+    if (ensure_scratch(c, 1, (size_t)chunk * (nh + 1) * 16)) return 1;
+    if (ensure_scratch(c, 2, (size_t)chunk * 8)) return 1;
+    double* fin = (double*)c->scratch[0];
+    double2* fout = (double2*)c->scratch[1];
+    double* mnorm = (double*)c->scratch[2];
+    const bool stage = (size_t)nh * sizeof(double) <= 64 * 1024;
+    const size_t lds = stage ? (size_t)nh * sizeof(double) : 0;
+    for (int r0 = 0; r0 < rows; r0 += chunk) {
+        const int nr = rows - r0 < chunk ? rows - r0 : chunk;
+        hipLaunchKernelGGL(table_integrand_kernel, dim3(nr), dim3(256), 0, c->stream, nxs, r0, xs, rho,
+                           (int)(rho_rows == 1), cmax, do_mass_norm, fin, mnorm);
+        HIP_TRY(hipGetLastError());
+        FftPlan* P = nullptr;
+        if (get_plan(c, nxs, nr, &P)) return 1;
+        void* ib[1] = {fin};
+        void* ob[1] = {fout};
+        FFT_TRY(rocfft_execution_info_set_stream(P->info, c->stream));
+        FFT_TRY(rocfft_execute(P->plan, ib, ob, P->info));
+        if (stage)
+            hipLaunchKernelGGL(interp_kernel<true>, dim3(nr), dim3(256), lds, c->stream, nm, nk, nh, r0, step,
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out);
+        else
+            hipLaunchKernelGGL(interp_kernel<false>, dim3(nr), dim3(256), 0, c->stream, nm, nk, nh, r0, step,
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 

@@ -21,6 +21,9 @@ from . import _native as nat
 from .cosmology import Cosmology
 from .params import battaglia_defaults, default_params
 from .quadrature import gradient_is_uniform, simpson_weights, trapz_weights
+from .functions import FN_BG_INTEGRAND, fn2d, ngal_from_mthresh, trapz_lastaxis
+from .functions import context as fn_context
+from .utils import vectorized_bisection_search
 
 _trapz = getattr(np, "trapezoid", None) or np.trapz
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -109,17 +112,9 @@ class HodEntry(MutableMapping):
         return len(set(self.dev) | set(self._vals))
 
 
-def duffy_concentration(m, z, A=None, alpha=None, beta=None, h=None):
-    """hmvec/hmvec.py:68-73 (host helper kept for API parity)."""
-    A = default_params["duffy_A_mean"] if A is None else A
-    alpha = default_params["duffy_alpha_mean"] if alpha is None else alpha
-    beta = default_params["duffy_beta_mean"] if beta is None else beta
-    h = default_params["H0"] / 100.0 if h is None else h
-    return A * ((h * m / 2.0e12) ** alpha) * (1 + z) ** beta
-
-
-def R_from_M(M, rho, delta):
-    """hmvec/hmvec.py:627-628."""
+def _R_from_M(M, rho, delta):
+    """hmvec/hmvec.py:627-628 for the handful of grid radii the constructor needs (host input
+    preparation; the public, device-backed R_from_M lives in functions.py)."""
     return (3.0 * M / 4.0 / np.pi / delta / rho) ** (1.0 / 3.0)
 
 
@@ -182,12 +177,12 @@ class HaloModel(Cosmology):
     def rvir(self, m, z):
         """Host helper with the reference's signature (hmvec/hmvec.py:111-115)."""
         if self.mdef == "vir":
-            return R_from_M(m, self.rho_critical_z(z), delta=self.deltav(z))
+            return _R_from_M(m, self.rho_critical_z(z), delta=self.deltav(z))
         elif self.mdef == "mean":
-            return R_from_M(m, self.rho_matter_z(z), delta=200.0)
+            return _R_from_M(m, self.rho_matter_z(z), delta=200.0)
 
     def R_of_m(self, ms):
-        return R_from_M(ms, self.rho_matter_z(0), delta=1.0)
+        return _R_from_M(ms, self.rho_matter_z(0), delta=1.0)
 
     # ------------------------------------------------------------------ device plumbing
     def _bump(self):
@@ -607,29 +602,24 @@ class HaloModel(Cosmology):
         """Bisection on log10 mthresh with the reference's GLOBAL stop test over z
         (hmvec/utils.py:9-42 called at hmvec/hmvec.py:426-433).  Every z keeps bisecting
         until all z meet rtol, so the answer depends on the whole z vector."""
-        lo = ngal * 0 + pparams["hod_bisection_search_min_log10mthresh"]
-        hi = ngal * 0 + pparams["hod_bisection_search_max_log10mthresh"]
-        rtol = pparams["hod_bisection_search_rtol"]
-        warn_iter = pparams["hod_bisection_search_warn_iter"]
-        mtol, i, warned = np.inf, 0, False
-        while np.any(np.abs(mtol) > rtol):
-            ynow = (lo + hi) / 2.0
-            xnow = self._hod_device(("hod", "_bisect"), ynow, pparams, "max")["ngal"].numpy()
-            mtol = (xnow - ngal) / ngal
-            lo[mtol > 0] = ynow[mtol > 0]          # "decreasing" relation
-            hi[mtol <= 0] = ynow[mtol <= 0]
-            i += 1
-            if (i > warn_iter) and not (warned):
-                print("WARNING: Bisection search has done more than ", warn_iter, " loops. Still searching...")
-                warned = True
-        print("Bisection search converged in ", i, " iterations.")
-        return ynow
+        def ngal_of(log10mthresh):       # the device HOD kernel's n_gal(z) for trial thresholds
+            return self._hod_device(("hod", "_bisect"), log10mthresh, pparams, "max")["ngal"].numpy()
+
+        return vectorized_bisection_search(ngal, ngal_of,
+                                           [pparams["hod_bisection_search_min_log10mthresh"],
+                                            pparams["hod_bisection_search_max_log10mthresh"]],
+                                           "decreasing", rtol=pparams["hod_bisection_search_rtol"], verbose=True,
+                                           hang_check_num_iter=pparams["hod_bisection_search_warn_iter"])
 
     def get_ngal(self, Nc, Ns):
-        return _trapz(self.nzm * (Nc + Ns), self.ms, axis=-1)
+        """hmvec/hmvec.py:462."""
+        with fn_context(self._ctx()):
+            return ngal_from_mthresh(nzm=self.nzm, ms=self.ms, Ncs=Nc, Nss=Ns)
 
     def get_bg(self, Nc, Ns, ngal):
-        return _trapz(self.nzm * (Nc + Ns) * self.bh, self.ms, axis=-1) / ngal
+        """hmvec/hmvec.py:464-466."""
+        with fn_context(self._ctx()):
+            return trapz_lastaxis(fn2d(FN_BG_INTEGRAND, [self.nzm, Nc, Ns, self.bh]), self.ms) / ngal
 
     # ------------------------------------------------------------------ spectra
     def _tracer(self, name, order):

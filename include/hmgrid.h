@@ -104,7 +104,7 @@ int hmg_halo_structure(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const d
                        double* d_rs /*[nz][nm]*/);
 
 /* ---- A7: mass-definition conversion -------------------------------------------------
- * Replaces mdelta_from_mdelta (hmvec/hmvec.py:748-798): secant solve in ln M2 of
+ * Replaces mdelta_from_mdelta (hmvec/hmvec.py:748-798): the root in ln M2 of
  *   M1 F(c1) = M2 F(c2),  c2 = c1 ((M2/M1)(drho1/drho2))^(1/3),  F = 1/(ln(1+c)-c/(1+c)),
  * drho2[z] = delta2 * rho2[z].  Also returns r2 = (3 M2/(4 pi delta2 rho2))^(1/3)
  * (hmvec.py:225).                                                                       */
@@ -227,6 +227,65 @@ int hmg_power_batch(hmg_ctx* ctx, int nz, int nm, int nk, int ntr, const hmg_tra
 int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, const double* d_zs,
                const double* d_ks, const double* d_Pzk, int ngz, const double* d_gzs,
                const double* d_pref, const double* d_chis, const double* d_wz, double* d_out);
+
+/* ---- module-level helpers of the path -------
+ * The reference exports its building blocks as free functions (hmvec/__init__.py:1 star-import);
+ * its own tests call them (bin/tests.py:11,27,268-295).  hmg_fn2d evaluates one of them over a
+ * (rows, cols) grid: element (r,c) of input i is d_in[i][r*h_sr[i] + c*h_sc[i]], so full arrays
+ * (sr=cols, sc=1), per-row (1,0), per-column (0,1) and scalar (0,0) operands broadcast as numpy
+ * would.  h_par are host scalars.  One fp64 output [rows][cols].                                 */
+#define HMG_FN_TINKER_BIAS    0  /* in nu; par delta                              tinker.py:26-40 */
+#define HMG_FN_TINKER_FNU     1  /* in nu, z, table_z[nt], table_alpha[nt] (strides ignored for
+                                    the two tables); par norm_consistency, alpha, nt  tinker.py:43-67 */
+#define HMG_FN_MHALO_STELLAR  2  /* in z, log10mstellar                        hmvec.py:648-695 */
+#define HMG_FN_HOD_NC         3  /* in log10mstar(m), log10mstar_thresh; par sigma  hmvec.py:698-703 */
+#define HMG_FN_HOD_NS         4  /* in Nc, log10mhalo, Msat, Mcut; par alphasat   hmvec.py:708-716 */
+#define HMG_FN_HOD_MFUNC      5  /* in log10mthresh; par Bamp, Bind                 hmvec.py:706 */
+#define HMG_FN_HOD_NSNSM1     6  /* in Nc, Ns; par corr (0 max, 1 min)            hmvec.py:719-725 */
+#define HMG_FN_HOD_NCNS       7  /* in Nc, Ns; par corr                           hmvec.py:727-731 */
+#define HMG_FN_FCON           8  /* in c                                            hmvec.py:737 */
+#define HMG_FN_RHO_NFW        9  /* in r, rhoscale, rs                            hmvec.py:744-746 */
+#define HMG_FN_R_FROM_M      10  /* in M, rho, delta                              hmvec.py:627-628 */
+#define HMG_FN_DUFFY         11  /* in m, z; par A, alpha, beta, h                 hmvec.py:68-73 */
+#define HMG_FN_BATT_FIT      12  /* in m200c, z; par A0, alpha_m, alpha_z         hmvec.py:800-802 */
+#define HMG_FN_RHO_GAS_X     13  /* in x, m200c, z, rhocritz; par omb, omm, gamma, fit[9]  :844-860 */
+#define HMG_FN_RHO_GAS_R     14  /* in r, m200c, z, rhocritz; same par                    :819-842 */
+#define HMG_FN_PE_X          15  /* in x, m200c, R200c, z, rhocritz; par omb, omm, alpha, gamma,
+                                    fit[9], G_newt                                hmvec.py:906-927 */
+#define HMG_FN_PE_R          16  /* in r, m200c, z, rhocritz; same par            hmvec.py:881-904 */
+#define HMG_FN_NGAL_INTEGRAND 17 /* in nzm, Nc, Ns -> nzm*(Nc+Ns)                   hmvec.py:956 */
+#define HMG_FN_A2Z           18  /* in a                                            hmvec.py:933 */
+#define HMG_FN_MDELTA        19  /* in M1, c1, delta_rho1, delta_rho2 -> M2        hmvec.py:748-798 */
+#define HMG_FN_BG_INTEGRAND  20  /* in nzm, Nc, Ns, bh -> nzm*(Nc+Ns)*bh            hmvec.py:464-466 */
+#define HMG_FN_COUNT         21
+#define HMG_FN_MAXIN   6
+#define HMG_FN_MAXPAR 16
+int hmg_fn2d(hmg_ctx* ctx, int op, int rows, int cols, int nin, const double* const* h_d_in,
+             const int* h_sr, const int* h_sc, const double* h_par, int npar, double* d_out);
+
+/* Mstellar_halo (hmvec/hmvec.py:634-646): per-redshift inverse of the SHMR through the
+ * reference's 4000-point table linspace(-18,18,4000) and np.interp (clamped ends).
+ * d_log10mhalo [nm] is shared by every z, as in the reference (it reads row 0).  -> [nz][nm]    */
+int hmg_mstellar_halo(hmg_ctx* ctx, int nz, int nm, const double* d_zs, const double* d_log10mhalo,
+                      double* d_out);
+
+/* np.trapz(y, x, axis=-1) for y [rows][cols], x [cols] (ngal_from_mthresh hmvec.py:957, the
+ * mass normalisation of uk_fft fft.py:15).  -> [rows]                                           */
+int hmg_trapz_rows(hmg_ctx* ctx, int rows, int cols, const double* d_y, const double* d_x, double* d_out);
+
+/* fft_integral (hmvec/fft.py:35-51): uk_j = -Im(rfft(x*y))_j * step, step = (x[n-1]-x[0])/n, for
+ * every row of y [rows][n]; d_uk [rows][n/2+1].  The wavenumbers 2*pi*rfftfreq(n, step) are a
+ * host one-liner and are left to the caller.                                                    */
+int hmg_sine_transform(hmg_ctx* ctx, int rows, int n, const double* d_x, const double* d_y, double* d_uk);
+
+/* generic_profile_fft (hmvec/fft.py:56-94) for a TABULATED integrand: d_rho is rho(x) on
+ * xs = linspace(0,xmax,nxs+1)[1:], either one row shared by all (z,m) (rho_rows == 1) or one row
+ * per (z,m) (rho_rows == nz*nm) - the two shapes the reference accepts (fft.py:75-78).  Truncation
+ * |x| > cmax, trapz mass norm, sine transform, k scaling and interpolation as hmg_profile_fft.  */
+int hmg_profile_fft_table(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_step,
+                          const double* d_xs, const double* d_kts, const double* d_rho, int rho_rows,
+                          const double* d_cmax, const double* d_rss, const double* d_zs,
+                          const double* d_ks, int do_mass_norm, double* d_out);
 
 /* ---- z-slab gather over RCCL/xGMI -------------------------------------------------
  * One communicator per context.  The 128-byte id comes from hmg_comm_unique_id on rank 0

@@ -1,0 +1,188 @@
+"""GPU mirrors of the reference's free functions (hmvec_amd.functions / .fft / .tinker / .utils)
+against outputs of the unmodified reference (tests/golden/func_pins.npz, unit_pins.npz), plus the
+reference's own self-checks that use them (bin/tests.py: test_fft_integral, test_battaglia,
+test_mcon; hmvec/utils.py:45-51)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+G = load_golden("func_pins")
+U = load_golden("unit_pins")
+Z, MS, RHOC, RHOM = G["z"], G["ms"], G["rhoc"], G["rhom"]
+OMB, OMM = 0.049, 0.315
+TOL = 2e-13          # generic pow/exp/log on two different libms
+
+
+def test_package_exports_reference_names():
+    import hmvec_amd as hm
+    for name in ("HaloModel", "duffy_concentration", "R_from_M", "Mstellar_halo", "Mhalo_stellar", "avg_Nc", "avg_Ns",
+                 "avg_NsNsm1", "avg_NcNs", "hod_default_mfunc", "Fcon", "rhoscale_nfw", "rho_nfw_x", "rho_nfw",
+                 "mdelta_from_mdelta", "mdelta_from_mdelta_unvectorized", "battaglia_gas_fit", "rho_gas",
+                 "rho_gas_generic", "rho_gas_generic_x", "P_e", "P_e_generic", "P_e_generic_x", "a2z",
+                 "ngal_from_mthresh", "default_params", "battaglia_defaults", "generic_profile_fft", "Cosmology"):
+        assert hasattr(hm, name), name
+    for mod, names in (("fft", ("fft_integral", "generic_profile_fft", "uk_fft", "analytic_fft_integral")),
+                       ("tinker", ("bias", "f_nu")), ("utils", ("vectorized_bisection_search",))):
+        for n in names:
+            assert hasattr(getattr(hm, mod), n), (mod, n)
+    with pytest.raises(NameError):       # the reference's rhoscale_nfw reads an undefined global
+        hm.rhoscale_nfw(1e14, 1.0, 5.0)
+
+
+def test_halo_structure_functions():
+    import hmvec_amd as hm
+    cs = hm.duffy_concentration(MS[None, :], Z[:, None])
+    assert cs.shape == (Z.size, MS.size) and rel_err(cs, G["duffy_default"]) < TOL
+    assert rel_err(hm.duffy_concentration(MS[None, :], Z[:, None], 7.85, -0.081, -0.71, 0.7), G["duffy_vir"]) < TOL
+    assert rel_err(hm.R_from_M(MS[None, :], RHOC[:, None], delta=200.0), G["R_from_M"]) < TOL
+    assert rel_err(hm.Fcon(G["duffy_default"]), G["Fcon"]) < TOL
+    assert rel_err(hm.rho_nfw(G["r"], 3.3e14, 0.31), G["rho_nfw"]) < TOL
+    assert rel_err(hm.rho_nfw_x(G["r"], 2.0), G["rho_nfw_x"]) < TOL
+    assert rel_err(hm.a2z(np.array([1.0, 0.5, 0.25])), G["a2z"]) < TOL
+    assert isinstance(hm.Fcon(5.0), float) and abs(hm.Fcon(5.0) - (np.log(6.0) - 5.0 / 6.0)) < 1e-15   # scalars stay scalars
+
+
+def test_mass_conversion():
+    """mdelta_from_mdelta: the reference stops its secant at 1.5e-8 in ln M2 (scipy newton default tol), so
+    its own output is only that close to the root; the device solve is exact to rounding."""
+    import hmvec_amd as hm
+    cs = G["duffy_default"]
+    got = hm.mdelta_from_mdelta(MS, cs, 200.0 * RHOM, 200.0 * RHOC)
+    assert got.shape == cs.shape and rel_err(got, G["mdelta"]) < 1e-7
+    # residual of the defining equation M1 F(c1) = M2 F(c2) at the returned root
+    F = lambda c: 1.0 / (np.log(1 + c) - c / (1 + c))    # noqa: E731
+    c2 = cs * ((got / MS[None, :]) * (RHOM / RHOC)[:, None]) ** (1.0 / 3.0)
+    assert np.max(np.abs(MS[None, :] * F(cs) / (got * F(c2)) - 1.0)) < 1e-14
+    # bin/tests.py test_mcon: vectorised and unvectorised agree
+    un = hm.mdelta_from_mdelta(MS, cs, 200.0 * RHOM, 200.0 * RHOC, vectorized=False)
+    assert np.array_equal(un, got)
+    el = hm.mdelta_from_mdelta_unvectorized(MS[None, :] + cs * 0, cs, 200.0 * RHOM[:, None], 200.0 * RHOC[:, None])
+    assert np.array_equal(el, got)
+
+
+def test_hod_functions():
+    import hmvec_amd as hm
+    lmh, zc, thr = np.log10(MS)[None, :], Z[:, None], G["hod_thr"]
+    assert rel_err(hm.Mhalo_stellar(U["shmr_z"], U["shmr_logmstar"]), U["shmr_Mhalo_stellar"]) < TOL
+    assert np.max(np.abs(hm.Mstellar_halo(U["shmr_z"], U["shmr_logmhalo"]) - U["shmr_Mstellar_halo"])) < 1e-12
+    Nc = hm.avg_Nc(lmh, zc, thr, 0.2)
+    assert np.allclose(Nc, G["avg_Nc"], rtol=1e-11, atol=1e-300)
+    Ns = hm.avg_Ns(lmh, zc, thr, G["avg_Nc"], 0.2, 1.0, 9.04, 0.74, 1.65, 0.59)
+    assert np.allclose(Ns, G["avg_Ns"], rtol=1e-12, atol=0)
+    assert np.allclose(hm.avg_Ns(lmh, zc, thr, None, 0.2, 1.1, 9.0, 0.7, 1.6, 0.6), G["avg_Ns_noNc"], rtol=1e-11, atol=1e-300)
+    assert rel_err(hm.hod_default_mfunc(hm.Mhalo_stellar(zc, thr), 9.04, 0.74), G["hod_mfunc"]) < 1e-12
+    for corr in ("max", "min"):
+        assert np.allclose(hm.avg_NsNsm1(G["avg_Nc"], G["avg_Ns"], corr), G[f"NsNsm1_{corr}"], rtol=1e-14, atol=0)
+        assert np.allclose(hm.avg_NcNs(G["avg_Nc"], G["avg_Ns"], corr), G[f"NcNs_{corr}"], rtol=1e-14, atol=0)
+    assert hm.avg_NcNs(G["avg_Nc"], G["avg_Ns"], "other") is None
+    ng = hm.ngal_from_mthresh(nzm=G["nzm"], ms=MS, Ncs=G["avg_Nc"], Nss=G["avg_Ns"])
+    assert rel_err(ng, G["ngal_from_NcNs"]) < 1e-13
+    ng = hm.ngal_from_mthresh(thr[:, 0], Z, G["nzm"], MS, 0.2, alphasat=1.0, Bsat=9.04, betasat=0.74, Bcut=1.65, betacut=0.59)
+    assert rel_err(ng, G["ngal_from_thr"]) < 1e-11
+    with pytest.raises(AssertionError):
+        hm.ngal_from_mthresh(thr[:, 0], nzm=G["nzm"], ms=MS, Ncs=G["avg_Nc"], Nss=G["avg_Ns"])
+
+
+def test_battaglia_functions():
+    import hmvec_amd as hm
+    m3, z3, rc3 = MS[None, :, None], Z[:, None, None], RHOC[:, None, None]
+    x, r = G["x"], G["r"]
+    assert rel_err(hm.battaglia_gas_fit(m3, z3, 4000.0, 0.29, -0.66), G["batt_fit"]) < TOL
+    got = hm.rho_gas_generic_x(x[None, None], m3, z3, OMB, OMM, rc3)
+    assert got.shape == (Z.size, MS.size, x.size) and rel_err(got, G["rho_gas_generic_x"]) < 1e-12
+    sh = hm.battaglia_defaults["SH"]
+    assert rel_err(hm.rho_gas_generic_x(x[None, None], m3, z3, OMB, OMM, rc3, gamma=-0.25, **sh), G["rho_gas_generic_x_SH"]) < 1e-12
+    assert rel_err(hm.rho_gas_generic(r[None, None], m3, z3, OMB, OMM, rc3), G["rho_gas_generic"]) < 1e-12
+    assert rel_err(hm.rho_gas(r, 1e13, 1.0, OMB, OMM, RHOC[1], profile="AGN"), G["rho_gas_AGN"]) < 1e-12
+    assert rel_err(hm.rho_gas(r, 1e13, 1.0, OMB, OMM, RHOC[1], profile="SH"), G["rho_gas_SH"]) < 1e-12
+    r200 = hm.R_from_M(m3, rc3, delta=200.0)
+    assert rel_err(hm.P_e_generic_x(x[None, None], m3, r200, z3, OMB, OMM, rc3), G["P_e_generic_x"]) < 1e-12
+    assert rel_err(hm.P_e_generic(r[None, None], m3, z3, OMB, OMM, rc3, alpha=1.1, gamma=-0.35), G["P_e_generic"]) < 1e-12
+    assert rel_err(hm.P_e(r, 2e14, 0.5, OMB, OMM, RHOC[1]), G["P_e"]) < 1e-12
+    with pytest.raises(TypeError):
+        hm.rho_gas_generic_x(x, 1e13, 1.0, OMB, OMM, RHOC[1], not_a_parameter=1.0)
+
+
+def test_battaglia_gas_mass_closure():
+    """bin/tests.py test_battaglia: the AGN gas profile integrated to R200c holds about the cosmic
+    baryon fraction of M200c (the reference prints this ratio)."""
+    import hmvec_amd as hm
+    r = np.geomspace(1e-4, 20.0, 10000)
+    rhocz = RHOC[1]
+    rhos = hm.rho_gas(r, 1e13, 1.0, OMB, OMM, rhocz, profile="AGN")
+    r200 = hm.R_from_M(1e13, rhocz, delta=200)
+    integrand = rhos * 4.0 * np.pi * r ** 2
+    integrand[r > r200] = 0
+    ratio = hm.functions.trapz_lastaxis(integrand, r) / (1e13 * OMB / OMM)
+    assert 0.3 < ratio < 1.2
+
+
+def test_tinker_functions():
+    import hmvec_amd as hm
+    assert rel_err(hm.tinker.bias(U["tinker_nu"]), U["tinker_bias"]) < TOL
+    assert rel_err(hm.tinker.f_nu(U["tinker_nu"], U["tinker_z"]), U["tinker_fnu"]) < 1e-12
+    with pytest.raises(ValueError):
+        hm.tinker.f_nu(U["tinker_nu"], U["tinker_z"] - 1.0)      # below the alpha(z) table (bounds_error=True)
+    raw = hm.tinker.f_nu(U["tinker_nu"], U["tinker_z"], norm_consistency=False)
+    assert np.all(np.isfinite(raw)) and raw.shape == U["tinker_nu"].shape
+
+
+def test_fft_integral_pins():
+    import hmvec_amd as hm
+    kt, u = hm.fft.fft_integral(U["fftint_x"], np.exp(-U["fftint_x"] ** 2 / 2.0))
+    assert np.array_equal(kt[:400], U["fftint_k"])
+    assert np.max(np.abs(u[:400] - U["fftint_u"])) < 1e-14
+    # the authors' known-answer check (bin/tests.py:8-18): sqrt(pi/2) k exp(-k^2/2) to the quirk level
+    sel = (kt > 0.5) & (kt < 3)
+    assert np.max(np.abs(u[sel] / hm.fft.analytic_fft_integral(kt[sel]) - 1)) < 2e-2
+    kt, u = hm.fft.fft_integral(G["fi_x"], G["fi_y"])
+    assert u.shape == (3, G["fi_x"].size // 2 + 1)
+    assert np.array_equal(kt[:300], G["fi_k"]) and np.max(np.abs(u[:, :300] - G["fi_u"])) < 1e-14
+
+
+def test_generic_profile_fft_with_user_callables():
+    import hmvec_amd as hm
+    cmax, rss, ks = G["gpf_cmax"], G["gpf_rss"], G["ks"]
+    k, u = hm.generic_profile_fft(lambda xx: 1.0 / xx / (1.0 + xx) ** 2, cmax, rss, Z, ks, 60.0, 3000)
+    assert k is ks or np.array_equal(k, ks)
+    assert np.max(np.abs(u - G["gpf_shared"])) < 1e-12
+    slope = G["gpf_slope"]
+    _, u = hm.fft.generic_profile_fft(lambda xx: xx ** -0.5 * (1.0 + xx) ** -slope, cmax, rss, Z, ks, 30.0, 1001)
+    assert np.max(np.abs(u - G["gpf_rows_odd_nxs"])) < 1e-12
+    _, u = hm.fft.generic_profile_fft(lambda xx: np.exp(-xx) + 0 * slope, 0 * cmax + 4.0, rss, Z, ks, 12.0, 640,
+                                      do_mass_norm=False)
+    assert rel_err(u, G["gpf_nonorm"]) < 1e-11
+    with pytest.raises(AssertionError):      # rhos.ndim must be 1 or 3 (hmvec/fft.py:75-78)
+        hm.generic_profile_fft(lambda xx: xx[None, :] + 0 * cmax[:, :1], cmax, rss, Z, ks, 10.0, 64)
+
+
+def test_uk_fft():
+    import hmvec_amd as hm
+    k, u = hm.fft.uk_fft(lambda rr: 1.0 / (rr / 0.2) / (1.0 + rr / 0.2) ** 2, 1.5, dr=0.01, rmax=40)
+    assert np.allclose(k[1:200], G["ukfft_k"], rtol=1e-15, atol=0)
+    assert np.max(np.abs(u[1:200] - G["ukfft_u"])) < 1e-12
+
+
+def test_bisection_self_test(capsys):
+    """hmvec/utils.py:45-51 plus the pinned iterate."""
+    import hmvec_amd as hm
+    xs = np.array([2.0, 4.0, 6.0])
+    d = hm.utils.vectorized_bisection_search(xs, lambda y: np.sqrt(y), (1, 40), "increasing", rtol=1e-4, verbose=True)
+    assert np.all(np.isclose(d, np.array([4.0, 16.0, 36.0]), rtol=1e-3))
+    assert np.array_equal(d, U["bisect_y"])
+    assert "Bisection search converged in" in capsys.readouterr().out
+
+
+def test_get_ngal_get_bg_methods():
+    import hmvec_amd as hm
+    zs = np.array([0.3, 1.1])
+    ms = np.geomspace(1e11, 1e16, 48)
+    h = hm.HaloModel(zs, np.geomspace(1e-3, 10, 8), ms=ms, accuracy="low", engine="analytic")
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    hod = h.hods["g"]
+    ng = h.get_ngal(hod["Nc"], hod["Ns"])
+    assert rel_err(ng, hod["ngal"]) < 1e-13
+    assert rel_err(h.get_bg(hod["Nc"], hod["Ns"], ng), hod["bg"]) < 1e-13

@@ -262,6 +262,91 @@ def run_unit_pins(hm):
     return out
 
 
+def run_function_pins(hm):
+    """Inputs and outputs of the reference's module-level helpers on the path (SURVEY 8a rows
+    A5, A7, A8, F1, F2, H1-H3, X1), on small grids that exercise their broadcasting."""
+    import hmvec.fft as rfft
+    out = {}
+    h = 0.673
+    rho_c0 = 2.77536627e11 * h ** 2
+    z1 = np.array([0.0, 0.6, 1.3, 2.9])
+    E2 = 0.315 * (1 + z1) ** 3 + 0.685
+    rhoc = rho_c0 * E2
+    rhom = rho_c0 * 0.315 * (1 + z1) ** 3
+    ms = np.geomspace(1e11, 3e15, 12)
+    out["z"], out["ms"], out["rhoc"], out["rhom"] = z1, ms, rhoc, rhom
+    cs = hm.duffy_concentration(ms[None, :], z1[:, None])
+    out["duffy_default"] = cs
+    out["duffy_vir"] = hm.duffy_concentration(ms[None, :], z1[:, None], 7.85, -0.081, -0.71, 0.7)
+    out["R_from_M"] = hm.R_from_M(ms[None, :], rhoc[:, None], delta=200.0)
+    out["Fcon"] = hm.Fcon(cs)
+    r = np.geomspace(1e-3, 5.0, 17)
+    out["r"] = r
+    out["rho_nfw"] = hm.rho_nfw(r, 3.3e14, 0.31)
+    out["rho_nfw_x"] = hm.rho_nfw_x(r, 2.0)
+    out["a2z"] = hm.a2z(np.array([1.0, 0.5, 0.25]))
+    out["mdelta"] = hm.mdelta_from_mdelta(ms, cs, 200.0 * rhom, 200.0 * rhoc)
+    out["mdelta_unvec"] = hm.mdelta_from_mdelta(ms, cs, 200.0 * rhom, 200.0 * rhoc, vectorized=False)
+    # HOD helpers with the shapes add_hod uses
+    lmh = np.log10(ms)[None, :]
+    zc = z1[:, None]
+    thr = np.array([10.2, 10.5, 10.9, 11.3])[:, None]
+    out["hod_thr"] = thr
+    Nc = hm.avg_Nc(lmh, zc, thr, 0.2)
+    Ns = hm.avg_Ns(lmh, zc, thr, Nc, 0.2, 1.0, 9.04, 0.74, 1.65, 0.59)
+    out["avg_Nc"], out["avg_Ns"] = Nc, Ns
+    out["avg_Ns_noNc"] = hm.avg_Ns(lmh, zc, thr, None, 0.2, 1.1, 9.0, 0.7, 1.6, 0.6)
+    out["hod_mfunc"] = hm.hod_default_mfunc(hm.Mhalo_stellar(zc, thr), 9.04, 0.74)
+    for corr in ("max", "min"):
+        out[f"NsNsm1_{corr}"] = hm.avg_NsNsm1(Nc, Ns, corr)
+        out[f"NcNs_{corr}"] = hm.avg_NcNs(Nc, Ns, corr)
+    nzm = 1e-3 * (ms[None, :] / 1e13) ** -1.9 * np.exp(-ms[None, :] / 1e15) / ms[None, :] * (1 + zc) ** -0.5
+    out["nzm"] = nzm
+    out["ngal_from_NcNs"] = hm.ngal_from_mthresh(nzm=nzm, ms=ms, Ncs=Nc, Nss=Ns)
+    out["ngal_from_thr"] = hm.ngal_from_mthresh(thr[:, 0], z1, nzm, ms, 0.2, alphasat=1.0, Bsat=9.04, betasat=0.74,
+                                                Bcut=1.65, betacut=0.59)
+    # Battaglia profiles with the (nz,nm,nxs) broadcasting add_battaglia_profile uses
+    omb, omm = 0.049, 0.315
+    x = np.linspace(0.0, 8.0, 9)[1:]
+    out["x"] = x
+    m3, z3, rc3 = ms[None, :, None], z1[:, None, None], rhoc[:, None, None]
+    out["batt_fit"] = hm.battaglia_gas_fit(m3, z3, 4000.0, 0.29, -0.66)
+    out["rho_gas_generic_x"] = hm.rho_gas_generic_x(x[None, None], m3, z3, omb, omm, rc3)
+    sh = hm.battaglia_defaults["SH"]
+    out["rho_gas_generic_x_SH"] = hm.rho_gas_generic_x(x[None, None], m3, z3, omb, omm, rc3, gamma=-0.25, **sh)
+    out["rho_gas_generic"] = hm.rho_gas_generic(r[None, None], m3, z3, omb, omm, rc3)
+    out["rho_gas_AGN"] = hm.rho_gas(r, 1e13, 1.0, omb, omm, rhoc[1], profile="AGN")
+    out["rho_gas_SH"] = hm.rho_gas(r, 1e13, 1.0, omb, omm, rhoc[1], profile="SH")
+    r200 = hm.R_from_M(m3, rc3, delta=200.0)
+    out["P_e_generic_x"] = hm.P_e_generic_x(x[None, None], m3, r200, z3, omb, omm, rc3)
+    out["P_e_generic"] = hm.P_e_generic(r[None, None], m3, z3, omb, omm, rc3, alpha=1.1, gamma=-0.35)
+    out["P_e"] = hm.P_e(r, 2e14, 0.5, omb, omm, rhoc[1])
+    # generic_profile_fft with user callables: shared 1-D profile, per-(z,m) 3-D profile, no mass norm
+    ks = np.geomspace(1e-3, 30.0, 21)
+    out["ks"] = ks
+    cmax = cs
+    rss = (hm.R_from_M(ms[None, :], rhoc[:, None], delta=200.0) / cs)[..., None]
+    out["gpf_cmax"], out["gpf_rss"] = cmax, rss
+    _, u1 = rfft.generic_profile_fft(lambda xx: 1.0 / xx / (1.0 + xx) ** 2, cmax, rss, z1, ks, 60.0, 3000)
+    out["gpf_shared"] = u1
+    slope = (2.0 + 0.1 * np.arange(ms.size))[None, :, None] + 0.05 * z1[:, None, None]
+    out["gpf_slope"] = slope
+    _, u3 = rfft.generic_profile_fft(lambda xx: xx ** -0.5 * (1.0 + xx) ** -slope, cmax, rss, z1, ks, 30.0, 1001)
+    out["gpf_rows_odd_nxs"] = u3
+    _, u4 = rfft.generic_profile_fft(lambda xx: np.exp(-xx) + 0 * slope, 0 * cmax + 4.0, rss, z1, ks, 12.0, 640,
+                                     do_mass_norm=False)
+    out["gpf_nonorm"] = u4
+    # fft_integral with a 2-D integrand
+    xx = np.arange(2e-3, 9.0, 2e-3)
+    yy = np.exp(-xx[None, :] ** 2 / np.array([2.0, 1.0, 0.5])[:, None])
+    kt, ukt = rfft.fft_integral(xx, yy)
+    out["fi_x"], out["fi_y"], out["fi_k"], out["fi_u"] = xx, yy, kt[:300], ukt[:, :300]
+    # uk_fft on an NFW profile (bin/tests.py:45)
+    kf, uf = rfft.uk_fft(lambda rr: 1.0 / (rr / 0.2) / (1.0 + rr / 0.2) ** 2, 1.5, dr=0.01, rmax=40)
+    out["ukfft_k"], out["ukfft_u"] = kf[1:200], uf[1:200]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -283,6 +368,7 @@ def main():
         print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
 
     save("unit_pins", run_unit_pins(hm))
+    save("func_pins", run_function_pins(hm))
 
     ks = np.geomspace(1e-4, 100, 40)
     ms = np.geomspace(2e10, 1e17, 32)
