@@ -369,29 +369,29 @@ __global__ void halo_structure_kernel(int nz, int nm, const double* __restrict__
 // ---------------------------------------------------------------- A7: mass conversion
 __device__ __forceinline__ double fcon(double c) { return log(1.0 + c) - c / (1.0 + c); }
 
-// Root of  g(l) = M1 F(c1) - e^l F(c2(l)),  F = 1/mu(c), mu(c) = ln(1+c) - c/(1+c),
-// c2(l) = c1 (e^l ratio / M1)^(1/3), in l = ln M2.  The reference lets scipy.optimize.newton
-// run a vectorised secant from l0 = ln M1 to |dl| < 1.5e-8 with a global stop test; the root
-// is the same, so it is found here by Newton with the analytic derivative
-//   g'(l) = -e^l/mu + e^l mu'(c2) (c2/3)/mu^2,   mu'(c) = c/(1+c)^2
-// (4-5 iterations to full precision instead of ~8 transcendental-heavy secant steps).
+// The reference solves M1 F(c1) = M2 F(c2), F = 1/mu(c), mu(c) = ln(1+c) - c/(1+c), for ln M2 with
+// c2 = c1 ((M2/M1) ratio)^(1/3) (scipy.optimize.newton without fprime: a vectorised secant from
+// ln M1 to |dl| < 1.5e-8 with a global stop test).  Eliminating M2 = M1 (c2/c1)^3 / ratio leaves
+// one equation in the new concentration alone,
+//     h(c) = c^3/mu(c) - K = 0,   K = ratio c1^3 / mu(c1),
+// solved here by Newton with h' = 3c^2/mu - c^4/((1+c)^2 mu^2): one logarithm per iteration, 4-5
+// iterations from c = c1 ratio^(1/3) (the secant's starting point M2 = M1) to rounding.  Same
+// root, so same M2 (to ~1e-15 instead of the secant's 1e-8).
 __device__ __forceinline__ double mdelta_solve(double M1, double c1, double ratio) {
-    const double lnM1 = log(M1), MF1 = M1 / fcon(c1);
-    const double kc = c1 * cbrt(ratio / M1);   // c2 = kc * e^(l/3)
-    double p1 = lnM1;
-    for (int it = 0; it < 40; ++it) {
-        const double e3 = exp(p1 * (1.0 / 3.0));
-        const double el = e3 * e3 * e3;
-        const double c2 = kc * e3;
-        const double opc2 = 1.0 + c2;
-        const double mu = log(opc2) - c2 / opc2;
-        const double g = MF1 - el / mu;
-        const double dg = el / mu * (c2 * c2 / (3.0 * opc2 * opc2 * mu) - 1.0);
-        const double dp = g / dg;
-        p1 -= dp;
-        if (fabs(dp) <= 2.0e-16 * fabs(p1)) break;
+    const double K = ratio * (c1 * c1 * c1) / fcon(c1);
+    double c = c1 * cbrt(ratio);
+    for (int it = 0; it < 16; ++it) {
+        const double ip = rcp_fast(1.0 + c);
+        const double q = c * ip;                    // c/(1+c)
+        const double mu = log1p(c) - q;
+        const double c2 = c * c;
+        // dc = h/h' with numerator and denominator multiplied by mu^2
+        const double dc = (c2 * c - K * mu) * mu * rcp_fast(c2 * (3.0 * mu - q * q));
+        c -= dc;
+        if (fabs(dc) <= 4.0e-15 * c) break;   // quadratic: the step just taken leaves an error ~dc^2/c
     }
-    return exp(p1);
+    const double s = c / c1;
+    return M1 * (s * s * s) / ratio;
 }
 
 __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
@@ -513,10 +513,12 @@ __device__ __forceinline__ void rowparams_body(int kind, int idx, double M, doub
                                                double rhoc, double hz, const RowFit& F, double gamma,
                                                double alpha_const, double pref, double post_pref,
                                                const RowOut& O) {
-    const double mr = M / 1.0e14;
-    const double X0 = F.f[0] * pow(mr, F.f[1]) * pow(z1, F.f[2]);
-    const double X1 = F.f[3] * pow(mr, F.f[4]) * pow(z1, F.f[5]);
-    const double X2 = F.f[6] * pow(mr, F.f[7]) * pow(z1, F.f[8]);
+    // A0 (M/1e14)^am (1+z)^az for the three fits: the two logarithms are shared and each power
+    // product is one exp2 (|exponent| < 10, so the result is within a few ulp of pow*pow)
+    const double lm = log2(M / 1.0e14), lz = log2(z1);
+    const double X0 = F.f[0] * exp2(F.f[1] * lm + F.f[2] * lz);
+    const double X1 = F.f[3] * exp2(F.f[4] * lm + F.f[5] * lz);
+    const double X2 = F.f[6] * exp2(F.f[7] * lm + F.f[8] * lz);
     if (kind == HMG_PROF_BATTAGLIA_GAS) {
         // (Ob/Om) rho_c rho0 x^g (1+x^alpha)^(-(beta+g)/alpha),  x = r/(R200c/2)
         O.amp[idx] = pref * rhoc * X0;
@@ -563,7 +565,7 @@ __global__ void rows_from_mvir_kernel(int kind, int nz, int nm, const double* __
     if (idx >= nz * nm) return;
     const int z = idx / nm, m = idx - z * nm;
     const double M2 = mdelta_solve(ms[m], cs[idx], d1[z] / (delta2 * rhoc[z]));
-    const double R2 = pow(3.0 * M2 / 4.0 / M_PI / delta2 / rhoc[z], 1.0 / 3.0);
+    const double R2 = cbrt(3.0 * M2 / 4.0 / M_PI / delta2 / rhoc[z]);
     m2[idx] = M2;
     r2[idx] = R2;
     rowparams_body(kind, idx, M2, R2, rvir[idx], 1.0 + zs[z], rhoc[z], hz ? hz[z] : 1.0, F, gamma,
