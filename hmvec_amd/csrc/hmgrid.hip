@@ -215,33 +215,49 @@ __global__ __launch_bounds__(64) void sigma2_mfma_kernel(int nz, int nzp, int nm
 #pragma unroll
     for (int b = 0; b < ZB; ++b) acc[b] = d4_t{0.0, 0.0, 0.0, 0.0};
     const int q_lo = seg * SIG_SEG_LEN, q_hi = min(nq, q_lo + SIG_SEG_LEN);
-    // four MFMA k-steps per trip: four independent window evaluations per lane in flight
-    for (int q0 = q_lo; q0 < q_hi; q0 += 16) {
-        double a[4];
-        int qi[4];
+    constexpr int NT = SIG_SEG_LEN / 16;      // trips of four MFMA k-steps
+    // Phase 1: every load of the segment - k', quadrature weight and the P rows - is issued up front
+    // (positions past the end of the segment are clamped and given zero weight), so the wave pays
+    // one memory latency instead of one per trip.
+    double kv[NT][4], wv[NT][4], pv[NT][4][ZB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int q = q0 + 4 * u + kk;
-            qi[u] = min(q, nq - 1);
-            const double kR = kq[qi[u]] * r;
-            double w;
-            if (kR < tswitch) {
-                const double xx = kR * kR;
-                w = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
-            } else {
-                double s, c;
-                if (kR < 1.0e9) sincos_fast(kR, s, c); else sincos(kR, &s, &c);
-                w = 3.0 * (s - kR * c) * rcp_fast(kR * kR * kR);
+            const int q = q_lo + 16 * t + 4 * u + kk;
+            const int qc = min(q, nq - 1);
+            kv[t][u] = kq[qc];
+            const double w = wq[qc];
+            wv[t][u] = (q < q_hi) ? w : 0.0;
+            const double* __restrict__ prow = PT + (size_t)qc * nzp + z0 + col;
+#pragma unroll
+            for (int b = 0; b < ZB; ++b) pv[t][u][b] = prow[16 * b];
+        }
+    // Phase 2: window values (branch-free: Taylor and trigonometric forms both evaluated, selected by
+    // kR; the library sincos is only called if some lane has kR >= 1e9) and the MFMA accumulation
+    // in the same k' order as before.
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        double a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double kR = kv[t][u] * r;
+            const double xx = kR * kR;
+            const double wt = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
+            double sn, cs;
+            sincos_fast(fmin(kR, 1.0e9), sn, cs);
+            if (__builtin_expect(__any(kR >= 1.0e9), 0)) {
+                if (kR >= 1.0e9) sincos(kR, &sn, &cs);
             }
-            a[u] = (q < q_hi) ? wq[qi[u]] * (w * w) : 0.0;
+            const double wtr = 3.0 * (sn - kR * cs) * rcp_fast(fmax(xx * kR, 1.0e-300));
+            const double w = (kR < tswitch) ? wt : wtr;
+            a[u] = wv[t][u] * (w * w);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double* __restrict__ prow = PT + (size_t)qi[u] * nzp + z0 + col;
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int b = 0; b < ZB; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(prow[16 * b], a[u], acc[b], 0, 0, 0);
-        }
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[t][u][b], a[u], acc[b], 0, 0, 0);
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
     if (m < nm) {
