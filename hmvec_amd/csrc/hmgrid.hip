@@ -783,14 +783,27 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     const double cm = A.cmax[row];
     const double inv_xc = 1.0 / XC;
     // ---- phase A: y_n = x_n rho(x_n) theta(x_n <= cmax) packed as (y_2p, y_2p+1); mass norm
+    // Pruned first pass: the integrand is zero beyond the truncation radius (85 % of a Battaglia
+    // row at xmax = 20).  When every packed sample p >= M/R0 is zero, the first radix-R0 pass
+    // sees (v0, 0, ..., 0) in every butterfly, whose DFT is v0 in all R0 outputs - exactly, in
+    // floating point - so phase A writes each sample straight into its R0 output slots and the
+    // pass (an LDS round trip, two barriers, the zero fill of the rest of the row) is skipped.
+    const int R0 = A.plan.radix[0];
+    const int stride0 = M / R0;
+    const bool pruned = A.plan.npass > 1 && A.xs[2 * stride0] > cm;   // xs is increasing
     double acc = 0.0;
-    for (int p = threadIdx.x; p < M; p += NT) {
+    for (int p = threadIdx.x; p < (pruned ? stride0 : M); p += NT) {
         const int j = 2 * p;
         const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
         double r0 = 0.0, r1 = 0.0;
         if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(xv.x, Aamp, inv_xc, AL, EX, A.gamma);
         if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(xv.y, Aamp, inv_xc, AL, EX, A.gamma);
-        buf[p] = cplx{xv.x * r0, xv.y * r1};
+        const cplx y = cplx{xv.x * r0, xv.y * r1};
+        if (pruned) {
+            for (int t = 0; t < R0; ++t) buf[R0 * p + t] = y;
+        } else {
+            buf[p] = y;
+        }
         if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
             const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
             acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
@@ -802,8 +815,8 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     }
     __syncthreads();
     // ---- phase B: in-place Stockham FFT of length M
-    int Ns = 1;
-    for (int ps = 0; ps < A.plan.npass; ++ps) {
+    int Ns = pruned ? R0 : 1;
+    for (int ps = pruned ? 1 : 0; ps < A.plan.npass; ++ps) {
         const int R = A.plan.radix[ps];
         // a pass whose butterflies fit one per thread uses the MAXB = 1 body (fewer live registers)
         const bool one = (M / R) <= NT;

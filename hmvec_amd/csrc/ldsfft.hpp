@@ -36,7 +36,10 @@ struct FftPlanDev {
     int radix[FFT_MAX_PASSES];
 };
 
-// Factor M into radices 5,4,3,2 (largest first).  Returns false if a larger prime remains.
+// Factor M into radices 5,4,3,2 (as few passes as possible: 4 before 2), then order the passes by
+// ascending radix.  The first pass is the one the fused profile kernel can skip when the input is
+// zero beyond sample M/R0 (truncated profiles): the smallest radix gives the loosest condition and
+// is the pass with the most butterflies.  Returns false if a larger prime remains.
 inline bool fft_make_plan(int M, FftPlanDev* p) {
     p->M = M;
     p->npass = 0;
@@ -50,6 +53,12 @@ inline bool fft_make_plan(int M, FftPlanDev* p) {
             rem /= r;
         }
     }
+    for (int i = 1; i < p->npass; ++i)          // insertion sort, ascending
+        for (int j = i; j > 0 && p->radix[j - 1] > p->radix[j]; --j) {
+            const int tmp = p->radix[j];
+            p->radix[j] = p->radix[j - 1];
+            p->radix[j - 1] = tmp;
+        }
     return rem == 1 && M >= 2;
 }
 
