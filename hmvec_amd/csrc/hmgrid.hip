@@ -436,18 +436,23 @@ __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
 // against 50-digit arithmetic for c in [0.5, 60]); it replaces two Si/Ci rational evaluations
 // and two sincos by 16 FMAs on about 2/3 of a typical grid, and it does not suffer the
 // cancellation of the closed form at small x.  a[row][0] = 0 flags "do not use" (c < 0.5).
-constexpr int NFW_NS = 16;
+constexpr int NFW_NS = 16;     // terms used for (1+c) x <= 4
+constexpr int NFW_NS2 = 32;    // terms used for 4 < (1+c) x <= NFW_X2 (same coefficient row, first 16 shared)
+constexpr double NFW_X2 = 10.0;
+// With 32 terms the series stays within 3e-15 (absolute, against 50-digit arithmetic, c in [0.5, 100])
+// up to (1+c) x = 10: the band 4 < (1+c) x <= 10 - where x itself is still on the small-argument
+// branch of Si/Ci, the most expensive case of the closed form - costs 32 FMAs instead.
 __global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, double* __restrict__ acoef) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
-    constexpr double INVFACT[NFW_NS] = {1.0, 0.16666666666666666, 0.008333333333333333, 0.0001984126984126984, 2.7557319223985893e-06, 2.505210838544172e-08, 1.6059043836821613e-10, 7.647163731819816e-13, 2.8114572543455206e-15, 8.22063524662433e-18, 1.9572941063391263e-20, 3.8681701706306835e-23, 6.446950284384474e-26, 9.183689863795546e-29, 1.1309962886447718e-31, 1.2161250415535181e-34};
+    constexpr double INVFACT[NFW_NS2] = {1.0, 0.16666666666666666, 0.008333333333333333, 0.0001984126984126984, 2.7557319223985893e-06, 2.505210838544172e-08, 1.6059043836821613e-10, 7.647163731819816e-13, 2.8114572543455206e-15, 8.22063524662433e-18, 1.9572941063391263e-20, 3.8681701706306835e-23, 6.446950284384474e-26, 9.183689863795546e-29, 1.1309962886447718e-31, 1.2161250415535181e-34, 1.151633562077195e-37, 9.67759295863189e-41, 7.265460179153071e-44, 4.902469756513544e-47, 2.9893108271424046e-50, 1.6552108677421951e-53, 8.359650847182804e-57, 3.866628513960594e-60, 1.643974708316579e-63, 6.446959640457174e-67, 2.3392451525606576e-70, 7.876246304918039e-74, 2.4674957095607893e-77, 7.210682961895936e-81, 1.9701319568021682e-84, 5.043860616493007e-88};
     const double c = cs[row], opc = 1.0 + c;
     const double mc = log(opc) - c / opc;
     const double inv_mc = 1.0 / mc;
-    double* a = acoef + (size_t)row * NFW_NS;
+    double* a = acoef + (size_t)row * NFW_NS2;
     double jm2 = c / opc, jm1 = mc, cp = c;   // J_0, J_1, c^(p-1) for p = 2
     a[0] = (c >= 0.5) ? 1.0 : 0.0;
-    for (int p = 2; p < 2 * NFW_NS; ++p) {
+    for (int p = 2; p < 2 * NFW_NS2; ++p) {
         const double jp = cp / (double)(p - 1) - 2.0 * jm1 - jm2;
         cp *= c;
         if (p & 1) {
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
     const double inv_mc = 1.0 / mc;
     const double inv_opc2 = 1.0 / (opc * opc);
     // small-argument series coefficients of this row: wave-uniform -> SGPRs
-    const double* __restrict__ a = acoef + (size_t)row * NFW_NS;
+    const double* __restrict__ a = acoef + (size_t)row * NFW_NS2;
     const bool use_series = (a[0] != 0.0);
     double* __restrict__ dst = uk + (size_t)row * nk;
     for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
@@ -495,6 +500,29 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
 #pragma unroll
             for (int n = NFW_NS - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
             dst[k] = u;
+            continue;
+        }
+        if (use_series && xc <= NFW_X2) {
+            const double z = x * x;
+            double u = fma_svs(a[NFW_NS2 - 1], z, a[NFW_NS2 - 2]);
+#pragma unroll
+            for (int n = NFW_NS2 - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
+            dst[k] = u;
+            continue;
+        }
+        if (x > 4.0 && xc < 1.0e9) {
+            // Both arguments on the auxiliary-function branch, Si = pi/2 - f cos - g sin,
+            // Ci = f sin - g cos.  Substituting into the NFW formula the terms in f(x) cancel and
+            // the rest collapses, exactly, to
+            //     u m_c = g(x) + f(xc) sin(c x) - g(xc) cos(c x) - sin(c x)/xc :
+            // one sincos (of c x, the argument the reference itself uses for sin(c x)) instead of
+            // two, three rationals instead of four, and none of the pi/2-sized cancellations.
+            const double zx = rcp_fast(x * x), zc = zx * inv_opc2;
+            double f1, g1, f2, g2, sd, cd;
+            sici_aux<false>(T, x, zx, f1, g1);
+            sici_aux<true>(T, xc, zc, f2, g2);
+            sincos_fast(c * x, sd, cd);
+            dst[k] = (g1 + (f2 - xc * zc) * sd - g2 * cd) * inv_mc;
             continue;
         }
         double s1, c1, s2, c2;
@@ -1959,7 +1987,7 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
     REQUIRE(ktile >= threads && ktile % threads == 0, "HMG_NFW_KTILE must be a multiple of the block size");
     const size_t blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
     REQUIRE(blocks <= 2147483647u, "grid too large");
-    if (ensure_scratch(c, 5, (size_t)nz * nm * NFW_NS * 8)) return 1;
+    if (ensure_scratch(c, 5, (size_t)nz * nm * NFW_NS2 * 8)) return 1;
     double* acoef = (double*)c->scratch[5];
     hipLaunchKernelGGL(nfw_series_kernel, grid1d((size_t)nz * nm, 128), dim3(128), 0, c->stream, nz * nm, cs, acoef);
     HIP_TRY(hipGetLastError());

@@ -128,6 +128,28 @@ __device__ __forceinline__ void sici_fast(const SiciTable* __restrict__ T, doubl
     ci = f * sx - g * cx;
 }
 
+// Auxiliary functions f(x), g(x) of Si/Ci for x > 4 (z = 1/x^2): the same Cephes rationals as in
+// sici_fast, returned on their own.  WANT_F = false evaluates g only.
+template <bool WANT_F>
+__device__ __forceinline__ void sici_aux(const SiciTable* __restrict__ T, double x, double z, double& f, double& g) {
+    double fn = 0.0, fd = 1.0, gn, gd;
+    if (x < 8.0) {
+        if (WANT_F) { fn = horner_s<7>(z, T->FN4); fd = x * horner1_s<7>(z, T->FD4); }
+        gn = z * horner_s<8>(z, T->GN4); gd = horner1_s<7>(z, T->GD4);
+    } else {
+        if (WANT_F) { fn = horner_s<9>(z, T->FN8); fd = x * horner1_s<8>(z, T->FD8); }
+        gn = z * horner_s<9>(z, T->GN8); gd = horner1_s<9>(z, T->GD8);
+    }
+    if (WANT_F) {
+        const double r = rcp_fast(fd * gd);
+        f = fn * (gd * r);
+        g = gn * (fd * r);
+    } else {
+        f = 0.0;
+        g = gn * rcp_fast(gd);
+    }
+}
+
 // Host copy of the table (uploaded once per context).
 inline SiciTable sici_table_host() {
     SiciTable t;
