@@ -1,0 +1,17 @@
+#!/bin/bash
+# A/B on one box: alternates the committed build (libhmgrid_base.so) and the working-tree build.
+# Usage: tools/ab_run.sh [rounds] [extra bench flags]
+set -e
+R=${1:-3}; shift || true
+for i in $(seq $R); do
+  for v in base new; do
+    if [ $v = base ]; then export HMG_LIB_PATH=$PWD/hmvec_amd/libhmgrid_base.so; else unset HMG_LIB_PATH; fi
+    python bench.py --no-cpu-baseline --detail --steps 30 "$@" > /tmp/ab_$v.json
+    python - $v <<'PY'
+import json, sys
+d = json.loads(open(f"/tmp/ab_{sys.argv[1]}.json").read().strip().splitlines()[-1])
+k = d["kernels"]
+print(f"{sys.argv[1]:5s} step {d['ms_per_step']:.4f}  power {d['roofline']['ms_per_launch']:.4f}  nfw {k['nfw_kernel']['ms']:.4f}  fused {k['profile_fused_kernel']['ms']:.4f}")
+PY
+  done
+done
