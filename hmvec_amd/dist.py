@@ -48,7 +48,7 @@ def exchange_unique_id(ctx, rank, world, tag):
             f.write(buf.raw)
         os.replace(tmp, path)
         return buf
-    deadline = time.time() + 120.0
+    deadline = time.time() + float(os.environ.get("HMG_RDZV_TIMEOUT", "600"))   # first library page-in on a fresh box can take minutes
     while time.time() < deadline:
         try:
             fresh = time.time() - os.path.getmtime(path) < 600.0
