@@ -1,0 +1,100 @@
+"""Seeded random configurations of the whole path, GPU vs the CPU oracle: grid sizes, mass and k
+ranges (low-mass/high-z halos with large concentrations, 1e16 halos with c ~ 1, k up to 1e3 so that
+every branch of the NFW evaluation - both series tiers, the Si/Ci closed form and the collapsed
+large-argument form - is hit), mass definition, mass function, feedback family, FFT lengths on both
+the workgroup-FFT and the rocFFT route, HOD correlation mode, miscentred centrals, pressure."""
+import numpy as np
+import pytest
+import scipy.constants as sc
+
+from conftest import merged_params, power_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(seed):
+    r = np.random.default_rng(seed)
+    nz, nm, nk = int(r.integers(1, 6)), int(r.integers(3, 40)), int(r.integers(2, 70))
+    zlo = float(r.uniform(0.0, 1.0))
+    zs = np.sort(r.uniform(zlo, zlo + r.uniform(0.1, 3.2), nz))
+    mlo = 10 ** r.uniform(9.5, 12.5)
+    ms = np.geomspace(mlo, mlo * 10 ** r.uniform(2.0, 5.5), nm)
+    klo = 10 ** r.uniform(-4.5, -1.0)
+    ks = np.geomspace(klo, klo * 10 ** r.uniform(2.0, 6.0), nk)
+    if r.random() < 0.3:                                   # irregular grids (non-uniform ln m: gradient stencil)
+        ms = np.sort(ms * np.exp(r.normal(0, 0.05, nm)))
+        ks = np.sort(ks * np.exp(r.normal(0, 0.02, nk)))
+    cfg = dict(zs=zs, ms=ms, ks=ks,
+               mdef=str(r.choice(["vir", "mean"])), mass_function=str(r.choice(["sheth-torman", "tinker"])),
+               family=str(r.choice(["AGN", "SH"])), nxs=int(r.choice([64, 200, 250, 1000, 90, 42, 77])),
+               xmax=float(r.choice([10.0, 20.0, 35.0])), corr=str(r.choice(["max", "min"])),
+               central=bool(r.random() < 0.4), pres=bool(r.random() < 0.5),
+               thr=10 ** r.uniform(9.8, 11.4, nz),
+               params=dict(omch2=float(r.uniform(0.10, 0.14)), H0=float(r.uniform(62, 74)),
+                           sigma2_numks=int(r.choice([1000, 1501, 4000]))))
+    if cfg["mass_function"] == "tinker":
+        cfg["zs"] = np.clip(cfg["zs"], 0.0, 2.99)           # alpha(z) table range
+        cfg["zs"] = np.unique(cfg["zs"])
+        cfg["thr"] = cfg["thr"][:cfg["zs"].size]
+    return cfg
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_configuration_against_oracle(seed, alpha_table):
+    import hmvec_amd as hm
+    from hmvec_amd.params import battaglia_defaults
+    from oracle import hmref
+    c = draw(seed)
+    zs, ms, ks = c["zs"], c["ms"], c["ks"]
+    h = hm.HaloModel(zs, ks, ms=ms, params=dict(c["params"]), mass_function=c["mass_function"], mdef=c["mdef"],
+                     accuracy="low", engine="analytic")
+    p = merged_params(c["params"])
+    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+    ci = hmref.CosmoInputs(h=h.h, omm0=h.omm0, ombh2=p["ombh2"], rho_crit_0=float(h.rho_critical_z(0.0)),
+                           rho_crit_zs=h.rho_critical_z(zs), Pzk=h.Pzk, sPzk=h.sPzk, ks_sigma2=ksig,
+                           h_of_z_zs=h.h_of_z(zs))
+    o = hmref.RefHaloModel(ci, zs, ks, ms, p, mass_function=c["mass_function"], mdef=c["mdef"], alpha_table=alpha_table)
+    assert rel_err(h.sigma2, o.sigma2) < 1e-12
+    assert np.allclose(h.nzm, o.nzm, rtol=1e-10, atol=1e-300) and rel_err(h.bh, o.bh) < 1e-12
+    assert np.max(np.abs(h.uk_profiles["nfw"] - o.uk_profiles["nfw"])) < 1e-12, "nfw"
+
+    h.add_battaglia_profile("electron", family=c["family"], xmax=c["xmax"], nxs=c["nxs"])
+    o.add_battaglia_profile("electron", c["family"], p["battaglia_gas_gamma"], battaglia_defaults[c["family"]],
+                            c["nxs"], c["xmax"])
+    assert np.max(np.abs(h.uk_profiles["electron"] - o.uk_profiles["electron"])) < 1e-12, "electron"
+    central = "electron" if c["central"] else None
+    h.add_hod("g", mthresh=c["thr"], corr=c["corr"], central_profile_name=central)
+    o.add_hod("g", mthresh=c["thr"], corr=c["corr"], central_profile_name=central)
+    for k in ("Nc", "Ns", "NsNsm1", "NcNs", "ngal", "bg"):
+        assert np.allclose(h.hods["g"][k], o.hods["g"][k], rtol=1e-10, atol=1e-290), k
+    names = ["nfw", "electron", "g"]
+    if c["pres"]:
+        h.add_battaglia_pres_profile("y", nxs=c["nxs"], xmax=c["xmax"])
+        sigT = sc.physical_constants["Thomson cross section"][0]
+        me = sc.physical_constants["electron mass"][0] / p["mSun"]
+        o.add_battaglia_pres_profile("y", p["battaglia_pres_alpha"], p["battaglia_pres_gamma"], battaglia_defaults["pres"],
+                                     c["nxs"], c["xmax"], sigT, me, sc.c)
+        ref = o.pk_profiles["y"]
+        tol = 1e-9 * np.abs(ref) + 1e-12 * np.max(np.abs(ref), axis=-1, keepdims=True)
+        assert np.all(np.abs(h.pk_profiles["y"] - ref) <= tol), "pressure profile"
+        names.append("y")
+    for i, a in enumerate(names):
+        for b in names[i:]:
+            ok, w = power_close(h.get_power(a, b), o.get_power(a, b))
+            assert ok, (a, b, w)
+
+
+def test_fuzz_draws_cover_every_nfw_branch():
+    """The sixteen draws together must exercise all four evaluation branches of nfw_kernel."""
+    import hmvec_amd as hm
+    hits = np.zeros(4)
+    for seed in range(16):
+        c = draw(seed)
+        h = hm.HaloModel(c["zs"], c["ks"], ms=c["ms"], params=dict(c["params"]), mdef=c["mdef"],
+                         accuracy="low", engine="analytic")
+        cs = h.concentration()
+        rs = h._d_rvir.numpy() / cs
+        x = c["ks"][None, None, :] * rs[..., None] * (1 + c["zs"][:, None, None])
+        xc = (1 + cs[..., None]) * x
+        hits += [np.sum(xc <= 4), np.sum((xc > 4) & (xc <= 10)), np.sum((xc > 10) & (x <= 4)), np.sum(x > 4)]
+    assert np.all(hits > 50), hits
