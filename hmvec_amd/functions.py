@@ -236,7 +236,7 @@ def ngal_from_mthresh(log10mthresh=None, zs=None, nzm=None, ms=None, sig_log_mst
     """n_gal(z) = int dm n(z,m) (Nc + Ns)  (hmvec/hmvec.py:936-957)."""
     if (Ncs is None) and (Nss is None):
         log10mstellar_thresh = np.asarray(log10mthresh)[:, None]
-        log10mhalo = fn_log10(ms)[None, :]
+        log10mhalo = np.log10(np.asarray(ms, dtype=np.float64))[None, :]     # input transform of the mass grid
         Ncs = avg_Nc(log10mhalo, np.asarray(zs)[:, None], log10mstellar_thresh, sig_log_mstellar)
         Nss = avg_Ns(log10mhalo, np.asarray(zs)[:, None], log10mstellar_thresh, Ncs, sig_log_mstellar, alphasat,
                      Bsat, betasat, Bcut, betacut, Msat_override=Msat_override, Mcut_override=Mcut_override)
@@ -246,11 +246,6 @@ def ngal_from_mthresh(log10mthresh=None, zs=None, nzm=None, ms=None, sig_log_mst
         assert sig_log_mstellar is None
     integrand = fn2d(FN_NGAL_INTEGRAND, [nzm, Ncs, Nss])
     return trapz_lastaxis(integrand, ms)
-
-
-def fn_log10(ms):
-    """log10 of the mass grid (an input transform, a handful of values: host)."""
-    return np.log10(np.asarray(ms, dtype=np.float64))
 
 
 # ------------------------------------------------------------------ Battaglia profiles (A8, X1)
