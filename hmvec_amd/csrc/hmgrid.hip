@@ -1505,8 +1505,10 @@ __global__ __launch_bounds__(256) void fn2d_kernel(FnArgs A) {
         y = 1.0 - Ay * (nua / (nua + pow(dc, ay))) + 0.183 * pow(nu, 1.5) + Cy * pow(nu, 2.4);
         break;
     }
-    case HMG_FN_TINKER_FNU: {
-        const double nu = X(0), zin = X(1);
+    case HMG_FN_TINKER_FNU:
+    case HMG_FN_TINKER_FSIGMA: {
+        const bool from_sigma2 = (A.op == HMG_FN_TINKER_FSIGMA);
+        const double nu = from_sigma2 ? par[3] / sqrt(X(0)) : X(0), zin = X(1);
         // zs*heaviside(3-zs,0) + 3*heaviside(zs-3,0): z<3 -> z, z==3 -> 0, z>3 -> 3 (tinker.py:53)
         const double z = zin < 3.0 ? zin : (zin > 3.0 ? 3.0 : 0.0);
         const double beta = 0.589 * pow(1.0 + z, 0.20), phi = -0.729 * pow(1.0 + z, -0.08);
@@ -1526,6 +1528,13 @@ __global__ __launch_bounds__(256) void fn2d_kernel(FnArgs A) {
             alpha = slope * (z - tz[lo]) + ta[lo];
         }
         y = alpha * un;
+        if (from_sigma2) y = nu * y;     // the mass function's f is nu * f_nu (hmvec.py:145)
+        break;
+    }
+    case HMG_FN_ST_FSIGMA: {
+        const double s2 = X(0), sig = sqrt(s2), sA = par[0], sa = par[1], sp = par[2], dc = par[3];
+        y = sA * sqrt(2.0 * sa / M_PI) * (1.0 + pow(s2 / sa / (dc * dc), sp)) * (dc / sig) *
+            exp(-sa * (dc * dc) / 2.0 / s2);
         break;
     }
     case HMG_FN_MHALO_STELLAR: {
@@ -2392,8 +2401,8 @@ int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const 
 // ---- function mirrors ------------------------------------------------------------------------
 int hmg_fn2d(hmg_ctx* c, int op, int rows, int cols, int nin, const double* const* in, const int* sr,
              const int* sc, const double* par, int npar, double* out) {
-    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4};
-    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0};
+    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4};
+    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4};
     REQUIRE(c && in && sr && sc && out, "NULL argument");
     REQUIRE(op >= 0 && op < HMG_FN_COUNT, "unknown function id");
     REQUIRE(rows > 0 && cols > 0, "empty grid");
@@ -2408,7 +2417,7 @@ int hmg_fn2d(hmg_ctx* c, int op, int rows, int cols, int nin, const double* cons
         A.in[i] = in[i]; A.sr[i] = sr[i]; A.sc[i] = sc[i];
     }
     for (int i = 0; i < HMG_FN_MAXPAR; ++i) A.par[i] = i < npar ? par[i] : 0.0;
-    if (op == HMG_FN_TINKER_FNU) REQUIRE(par[0] == 0.0 || par[2] >= 2.0, "alpha table needs >= 2 rows");
+    if (op == HMG_FN_TINKER_FNU || op == HMG_FN_TINKER_FSIGMA) REQUIRE(par[0] == 0.0 || par[2] >= 2.0, "alpha table needs >= 2 rows");
     if (op == HMG_FN_HOD_NSNSM1 || op == HMG_FN_HOD_NCNS) REQUIRE(par[0] == 0.0 || par[0] == 1.0, "corr must be 0 (max) or 1 (min)");
     hipLaunchKernelGGL(fn2d_kernel, grid1d((size_t)rows * cols, 256), dim3(256), 0, c->stream, A);
     HIP_TRY(hipGetLastError());

@@ -21,7 +21,7 @@ from . import _native as nat
 from .cosmology import Cosmology
 from .params import battaglia_defaults, default_params
 from .quadrature import gradient_is_uniform, simpson_weights, trapz_weights
-from .functions import FN_BG_INTEGRAND, fn2d, ngal_from_mthresh, trapz_lastaxis
+from .functions import FN_BG_INTEGRAND, FN_ST_FSIGMA, FN_TINKER_FSIGMA, fn2d, ngal_from_mthresh, trapz_lastaxis
 from .functions import context as fn_context
 from .utils import vectorized_bisection_search
 
@@ -350,7 +350,18 @@ class HaloModel(Cosmology):
         self._m200c_valid = False
 
     def get_fsigmaz(self):
-        raise NotImplementedError("fused into hmg_massfn; read .nzm / .bh")
+        """Multiplicity function f(sigma, z) on the (z,m) grid (hmvec/hmvec.py:133-147).  The path
+        itself never materialises it (hmg_massfn goes from sigma^2 straight to n and b); this
+        getter evaluates it on the device for callers that ask."""
+        dc = self.p["st_deltac"]
+        with fn_context(self._ctx()):
+            if self.mode == "sheth-torman":
+                return fn2d(FN_ST_FSIGMA, [self.sigma2], [self.p["st_A"], self.p["st_a"], self.p["st_p"], dc])
+            if self.mode == "tinker":
+                tz, ta = _tinker_alpha_table()
+                return fn2d(FN_TINKER_FSIGMA, [self.sigma2, self.zs[:, None]], [1.0, 0.368, float(tz.size), dc],
+                            tables=(tz, ta))
+        raise NotImplementedError
 
     def get_bh(self):
         return self.bh

@@ -257,7 +257,10 @@ int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, co
 #define HMG_FN_A2Z           18  /* in a                                            hmvec.py:933 */
 #define HMG_FN_MDELTA        19  /* in M1, c1, delta_rho1, delta_rho2 -> M2        hmvec.py:748-798 */
 #define HMG_FN_BG_INTEGRAND  20  /* in nzm, Nc, Ns, bh -> nzm*(Nc+Ns)*bh            hmvec.py:464-466 */
-#define HMG_FN_COUNT         21
+#define HMG_FN_ST_FSIGMA     21  /* in sigma2; par st_A, st_a, st_p, deltac  (get_fsigmaz, ST)  hmvec.py:136-141 */
+#define HMG_FN_TINKER_FSIGMA 22  /* in sigma2, z, table_z, table_alpha; par as TINKER_FNU + deltac:
+                                    nu f_nu(nu, z) with nu = deltac/sigma   (get_fsigmaz)      hmvec.py:142-145 */
+#define HMG_FN_COUNT         23
 #define HMG_FN_MAXIN   6
 #define HMG_FN_MAXPAR 16
 int hmg_fn2d(hmg_ctx* ctx, int op, int rows, int cols, int nin, const double* const* h_d_in,

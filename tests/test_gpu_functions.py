@@ -186,3 +186,20 @@ def test_get_ngal_get_bg_methods():
     ng = h.get_ngal(hod["Nc"], hod["Ns"])
     assert rel_err(ng, hod["ngal"]) < 1e-13
     assert rel_err(h.get_bg(hod["Nc"], hod["Ns"], ng), hod["bg"]) < 1e-13
+
+
+@pytest.mark.parametrize("mode", ["sheth-torman", "tinker"])
+def test_get_fsigmaz_reproduces_the_mass_function(mode):
+    """n(z,m) = rho_m0 f(sigma,z) (dln sigma^-1 / dln m) / m^2 (hmvec/hmvec.py:178-185) with f from the
+    device-backed getter and numpy's gradient."""
+    import hmvec_amd as hm
+    zs = np.array([0.0, 0.9, 2.4])
+    ms = np.geomspace(1e11, 1e16, 40)
+    h = hm.HaloModel(zs, np.geomspace(1e-3, 10, 8), ms=ms, mass_function=mode, accuracy="low", engine="analytic",
+                     skip_nfw=True)
+    f = h.get_fsigmaz()
+    assert f.shape == (3, 40) and np.all(f > 0)
+    ln_sigma_inv = -0.5 * np.log(h.sigma2)
+    n = h.rho_matter_z(0) * f * np.gradient(ln_sigma_inv, np.log(ms), axis=-1) / ms[None] ** 2
+    assert np.allclose(n, h.nzm, rtol=1e-11, atol=0)
+    assert np.array_equal(h.get_nzm(), h.nzm) and np.array_equal(h.get_bh(), h.bh)
