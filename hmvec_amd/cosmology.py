@@ -26,6 +26,29 @@ def a2z(a):
     return (1.0 / np.atleast_1d(a)) - 1.0
 
 
+def Wkr_taylor(kR):
+    """Small-argument form of the top-hat window (hmvec/cosmology.py:30-32)."""
+    from .functions import FN_WKR, fn2d
+    return fn2d(FN_WKR, [kR, 1.0], [np.inf])
+
+
+def Wkr(k, R, taylor_switch=default_params["Wkr_taylor_switch"]):
+    """Fourier transform of the real-space top hat, 3 (sin kR - kR cos kR)/(kR)^3 with the Taylor
+    branch below ``taylor_switch`` (hmvec/cosmology.py:34-38); evaluated on the device."""
+    from .functions import FN_WKR, fn2d
+    return fn2d(FN_WKR, [k, R], [taylor_switch])
+
+
+def limber_integral(ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis):
+    """Module-level form of the Limber projection (hmvec/cosmology.py:867-904) on the default device
+    context; ``Cosmology.limber_integral`` is the same code on the model's own context."""
+    return _limber(nat.default_context(0), ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis)
+
+
+def get_eds_model(fb=0.15, H0=68.0, YHe=0.25):
+    raise NotImplementedError("get_eds_model builds a CAMB parameter set (hmvec/cosmology.py:40-49); not on the path")
+
+
 class Cosmology(object):
     """``Cosmology(params, halofit, engine, accuracy)`` as in hmvec/cosmology.py:51-65.
 
@@ -366,24 +389,96 @@ class Cosmology(object):
         """C(ell) = int dz (H/c) W1 W2 P(z, k=(ell+1/2)/chi) / chi^2 on the GPU (hmg_limber);
         argument meaning as hmvec/cosmology.py:867-904.  Pzks may be a numpy (nz,nk) array or
         a DeviceArray already resident in HBM."""
-        ells = np.ascontiguousarray(ells, dtype=np.float64)
-        zs = np.atleast_1d(np.asarray(zs, dtype=np.float64))
-        ks = np.asarray(ks, dtype=np.float64)
-        gzs = np.atleast_1d(np.asarray(gzs, dtype=np.float64)).reshape(-1)
-        hzs = np.array(hzs, dtype=np.float64).reshape(-1)
-        chis = np.array(chis, dtype=np.float64).reshape(-1)
-        W1 = np.array(Wz1s, dtype=np.float64).reshape(-1)
-        W2 = np.array(Wz2s, dtype=np.float64).reshape(-1)
-        pref = (hzs * W1 * W2 / chis ** 2.0) + 0.0 * gzs
-        if zs.size == 1:
-            kev = (ells[:, None] + 0.5) / chis[None, :]
-            if np.any(kev < ks[0]) or np.any(kev > ks[-1]):
-                raise ValueError("A value in x_new is outside the interpolation range.")  # interp1d
-        wz = trapz_weights(gzs) if gzs.size > 1 else np.ones(1)
-        ctx = self._ctx()
-        dP = Pzks if isinstance(Pzks, nat.DeviceArray) else ctx.upload(np.asarray(Pzks, dtype=np.float64))
-        d = [ctx.upload(a) for a in (ells, zs, ks, gzs, pref, chis + 0.0 * gzs, wz)]
-        out = ctx.empty((ells.size,))
-        ctx.call("hmg_limber", ells.size, d[0].ptr, zs.size, ks.size, d[1].ptr, d[2].ptr, dP.ptr,
-                 gzs.size, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr, out.ptr)
-        return out.numpy().reshape(np.shape(ells))
+        return _limber(self._ctx(), ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis)
+
+    def C_gy(self, ells, zs, ks, Pgp, gzs, gdndz=None, zmin=None, zmax=None):
+        """Galaxy x Compton-y projection.  The reference's body (hmvec/cosmology.py:570-583) reads
+        two undefined names (``dndz``, ``Ppy``) and raises NameError on every call; this is the
+        computation its signature and its siblings C_gg / C_ky imply: galaxy window x unit window."""
+        gzs = np.asarray(gzs, dtype=np.float64)
+        chis = self.comoving_radial_distance(gzs)
+        hzs = self.h_of_z(gzs)
+        if gzs.size > 1:
+            Wz2s = gdndz / _trapz(gdndz, gzs)
+        else:
+            dchi = self.comoving_radial_distance(zmax) - self.comoving_radial_distance(zmin)
+            Wz2s = 1.0 / dchi / hzs
+        return self.limber_integral(ells, zs, ks, Pgp, gzs, 1, Wz2s, hzs, chis)
+
+    # ------------------------------------------------------------------ small derived quantities
+    def _baryon_cdm_fractions(self):
+        omtoth2 = self.p["omch2"] + self.p["ombh2"]
+        return self.p["omch2"] / omtoth2, self.p["ombh2"] / omtoth2
+
+    def total_matter_power_spectrum(self, Pnn, Pne, Pee):
+        """fc^2 Pnn + 2 fc fb Pne + fb^2 Pee with the CDM and baryon mass fractions
+        (hmvec/cosmology.py:621-630; examples/lensing_baryons.py)."""
+        from .functions import FN_LINCOMB3, context, fn2d
+        fc, fb = self._baryon_cdm_fractions()
+        with context(self._ctx()):
+            return fn2d(FN_LINCOMB3, [Pnn, Pne, Pee], [fc ** 2.0, 2.0 * fc * fb, fb * fb])
+
+    def total_matter_galaxy_power_spectrum(self, Pgn, Pge):
+        """fc Pgn + fb Pge (hmvec/cosmology.py:651-658)."""
+        from .functions import FN_LINCOMB3, context, fn2d
+        fc, fb = self._baryon_cdm_fractions()
+        with context(self._ctx()):
+            return fn2d(FN_LINCOMB3, [Pgn, Pge, 0.0], [fc, fb, 0.0])
+
+    def get_sigma8(self, zs, exact=False, kmin=1e-4, kmax=None, Ws=None, numks=1000, ret_pk=False):
+        """sigma(R = 8/h Mpc, z) through get_sigma2_R (hmvec/cosmology.py:271-286)."""
+        zs = np.atleast_1d(zs)
+        if exact:
+            raise NotImplementedError("exact sigma8 needs CAMB/CLASS transfer outputs")
+        r = self.get_sigma2_R(8.0 / self.p["H0"] * 100.0, zs, kmin=kmin, kmax=kmax, Ws=Ws, numks=numks, ret_pk=ret_pk)
+        if ret_pk:
+            return np.sqrt(r[0]), r[1], r[2]
+        return np.sqrt(r)
+
+    def sigma_crit(self, zlens, zsource):
+        """Critical surface density, Msun/Mpc^2 (hmvec/cosmology.py:95-101)."""
+        Gval = 4.517e-48   # Newton G in Mpc, seconds, Msun units
+        cval = 9.716e-15   # speed of light in Mpc, second units
+        Dd = self.angular_diameter_distance(zlens)
+        Ds = self.angular_diameter_distance(zsource)
+        Dds = np.asarray([self.angular_diameter_distance(zl, zsource) for zl in zlens])
+        return cval ** 2 * Ds / 4 / np.pi / Gval / Dd / Dds
+
+    def bias_fnl(self, bg, fnl, z, ks, deltac=1.42):
+        """Scale-dependent bias from local f_NL (hmvec/cosmology.py:132-136)."""
+        beta = 2.0 * deltac * (bg - 1.0)
+        a = 1.0 / (1 + z)
+        alpha = (2.0 * ks ** 2.0 * self.Tk(ks, type="eisenhu_osc")) / (3.0 * self.omm0 * self.h_of_z(0) ** 2.0) \
+            * self.D_growth(a, type="anorm", exact=False)
+        return bg + fnl * (beta / alpha)
+
+    def P_mm_linear(self, zs, ks):
+        """Placeholder in the reference too (hmvec/cosmology.py:104-105: ``pass``)."""
+        return None
+
+    def P_mm_nonlinear(self, ks, zs, halofit_version="mead"):
+        """Placeholder in the reference too (hmvec/cosmology.py:107-108: ``pass``)."""
+        return None
+
+
+def _limber(ctx, ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis):
+    ells = np.ascontiguousarray(ells, dtype=np.float64)
+    zs = np.atleast_1d(np.asarray(zs, dtype=np.float64))
+    ks = np.asarray(ks, dtype=np.float64)
+    gzs = np.atleast_1d(np.asarray(gzs, dtype=np.float64)).reshape(-1)
+    hzs = np.array(hzs, dtype=np.float64).reshape(-1)
+    chis = np.array(chis, dtype=np.float64).reshape(-1)
+    W1 = np.array(Wz1s, dtype=np.float64).reshape(-1)
+    W2 = np.array(Wz2s, dtype=np.float64).reshape(-1)
+    pref = (hzs * W1 * W2 / chis ** 2.0) + 0.0 * gzs
+    if zs.size == 1:
+        kev = (ells[:, None] + 0.5) / chis[None, :]
+        if np.any(kev < ks[0]) or np.any(kev > ks[-1]):
+            raise ValueError("A value in x_new is outside the interpolation range.")  # interp1d
+    wz = trapz_weights(gzs) if gzs.size > 1 else np.ones(1)
+    dP = Pzks if isinstance(Pzks, nat.DeviceArray) else ctx.upload(np.asarray(Pzks, dtype=np.float64))
+    d = [ctx.upload(a) for a in (ells, zs, ks, gzs, pref, chis + 0.0 * gzs, wz)]
+    out = ctx.empty((ells.size,))
+    ctx.call("hmg_limber", ells.size, d[0].ptr, zs.size, ks.size, d[1].ptr, d[2].ptr, dP.ptr,
+             gzs.size, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr, out.ptr)
+    return out.numpy().reshape(np.shape(ells))

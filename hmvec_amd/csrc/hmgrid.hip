@@ -1624,6 +1624,19 @@ __global__ __launch_bounds__(256) void fn2d_kernel(FnArgs A) {
     case HMG_FN_BG_INTEGRAND:
         y = X(0) * (X(1) + X(2)) * X(3);
         break;
+    case HMG_FN_WKR: {
+        const double kR = X(0) * X(1);
+        if (kR < par[0]) {
+            const double xx = kR * kR;
+            y = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
+        } else {
+            y = 3.0 * (sin(kR) - kR * cos(kR)) / (kR * kR * kR);
+        }
+        break;
+    }
+    case HMG_FN_LINCOMB3:
+        y = par[0] * X(0) + par[1] * X(1) + par[2] * X(2);
+        break;
     }
     A.out[idx] = y;
 }
@@ -2401,8 +2414,8 @@ int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const 
 // ---- function mirrors ------------------------------------------------------------------------
 int hmg_fn2d(hmg_ctx* c, int op, int rows, int cols, int nin, const double* const* in, const int* sr,
              const int* sc, const double* par, int npar, double* out) {
-    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4};
-    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4};
+    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4, 2, 3};
+    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4, 1, 3};
     REQUIRE(c && in && sr && sc && out, "NULL argument");
     REQUIRE(op >= 0 && op < HMG_FN_COUNT, "unknown function id");
     REQUIRE(rows > 0 && cols > 0, "empty grid");

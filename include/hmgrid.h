@@ -260,7 +260,10 @@ int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, co
 #define HMG_FN_ST_FSIGMA     21  /* in sigma2; par st_A, st_a, st_p, deltac  (get_fsigmaz, ST)  hmvec.py:136-141 */
 #define HMG_FN_TINKER_FSIGMA 22  /* in sigma2, z, table_z, table_alpha; par as TINKER_FNU + deltac:
                                     nu f_nu(nu, z) with nu = deltac/sigma   (get_fsigmaz)      hmvec.py:142-145 */
-#define HMG_FN_COUNT         23
+#define HMG_FN_WKR           23  /* in k, R; par taylor_switch: Fourier top-hat W(kR)    cosmology.py:30-38 */
+#define HMG_FN_LINCOMB3      24  /* in X0, X1, X2; par a, b, c -> a X0 + b X1 + c X2
+                                    (total_matter_power_spectrum etc.)                 cosmology.py:599-658 */
+#define HMG_FN_COUNT         25
 #define HMG_FN_MAXIN   6
 #define HMG_FN_MAXPAR 16
 int hmg_fn2d(hmg_ctx* ctx, int op, int rows, int cols, int nin, const double* const* h_d_in,

@@ -203,3 +203,42 @@ def test_get_fsigmaz_reproduces_the_mass_function(mode):
     n = h.rho_matter_z(0) * f * np.gradient(ln_sigma_inv, np.log(ms), axis=-1) / ms[None] ** 2
     assert np.allclose(n, h.nzm, rtol=1e-11, atol=0)
     assert np.array_equal(h.get_nzm(), h.nzm) and np.array_equal(h.get_bh(), h.bh)
+
+
+def test_cosmology_layer_names():
+    """Module-level Wkr / Wkr_taylor / limber_integral and the small Cosmology methods consumers use
+    (examples/lensing_baryons.py: total_matter_power_spectrum, total_matter_galaxy_power_spectrum)."""
+    import hmvec_amd as hm
+    from hmvec_amd import cosmology as hc
+    k = np.geomspace(1e-4, 50, 200)[None, :]
+    R = np.array([0.5, 3.0, 20.0])[:, None]
+    kR = k * R
+    ref = 3.0 * (np.sin(kR) - kR * np.cos(kR)) / kR ** 3.0
+    small = kR < 0.01
+    ref[small] = 1 - 0.1 * kR[small] ** 2 + 0.00357142857143 * kR[small] ** 4
+    assert np.allclose(hc.Wkr(k, R), ref, rtol=1e-13, atol=1e-15)
+    assert np.allclose(hc.Wkr_taylor(kR[small]), ref[small], rtol=1e-15, atol=0)
+    zs = np.linspace(0.1, 2.0, 6)
+    ks = np.geomspace(1e-3, 20, 40)
+    h = hm.HaloModel(zs, ks, ms=np.geomspace(1e11, 1e16, 32), accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", nxs=200, xmax=20)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+    Pnn, Pne, Pee = h.get_power("nfw"), h.get_power("nfw", "electron"), h.get_power("electron")
+    fc = h.p["omch2"] / (h.p["omch2"] + h.p["ombh2"])
+    fb = 1 - fc
+    assert np.allclose(h.total_matter_power_spectrum(Pnn, Pne, Pee), fc ** 2 * Pnn + 2 * fc * fb * Pne + fb ** 2 * Pee,
+                       rtol=1e-14, atol=0)
+    Pgn, Pge = h.get_power("g", "nfw"), h.get_power("g", "electron")
+    assert np.allclose(h.total_matter_galaxy_power_spectrum(Pgn, Pge), fc * Pgn + fb * Pge, rtol=1e-14, atol=0)
+    s8 = h.get_sigma8(zs)
+    assert s8.shape == (6, 1) and np.all(np.diff(s8[:, 0]) < 0) and 0.5 < s8[0, 0] < 1.2   # (nz,1) as the reference
+    assert np.allclose(s8 ** 2, h.get_sigma2_R(8.0 / h.p["H0"] * 100.0, zs, kmin=1e-4, numks=1000), rtol=1e-14)
+    ells = np.linspace(100, 3000, 50)
+    chis, hzs = h.comoving_radial_distance(zs), h.h_of_z(zs)
+    w = h.lensing_window(zs, 2.5)
+    a = hc.limber_integral(ells, zs, ks, Pnn, zs, w, w, hzs, chis)
+    assert np.array_equal(a, h.C_kk(ells, zs, ks, Pnn, lzs1=2.5, lzs2=2.5))
+    dndz = np.exp(-0.5 * ((zs - 1.0) / 0.4) ** 2)
+    cgy = h.C_gy(ells, zs, ks, Pge, zs, gdndz=dndz)
+    assert np.allclose(cgy, h.limber_integral(ells, zs, ks, Pge, zs, 1, dndz / (getattr(np, "trapezoid", None) or np.trapz)(dndz, zs), hzs, chis), rtol=1e-14)
+    assert h.P_mm_linear(zs, ks) is None and np.all(h.sigma_crit(zs[:2], 2.5) > 0)
