@@ -191,3 +191,68 @@ def test_ksz_consumer_call_sequence():
                             (aPgg, ("g", "g", {})), (aPge, ("g", "e", {}))):
         ok, w = power_close(got, o.get_power(a, b, **kw))
         assert ok, (a, b, kw.keys(), w)
+
+
+def test_lensing_baryons_example_sequence():
+    """examples/lensing_baryons.py, the reference's worked example, line for line (minus the plots;
+    `accuracy='low'` because CAMB is not in this image): HOD by number density on a 20-redshift grid,
+    a Battaglia profile with nxs=30000 / xmax=50 (too long for the workgroup FFT: the rocFFT route at
+    full size), total-matter combinations, and galaxy-galaxy lensing / cosmic shear Limber ratios -
+    each quantity against the oracle."""
+    import hmvec_amd as hm
+    from hmvec_amd.params import battaglia_defaults
+    from oracle import hmref
+    zgalaxy, zsource, ngal = 0.6, 1.0, 1e-4
+    zs = np.linspace(0.01, zsource + 1, 20)
+    ms = np.geomspace(2e10, 1e17, 100)
+    ks = np.geomspace(1e-4, 100, 1001)
+    hcos = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    hcos.add_hod("g", ngal=ngal + zs * 0.0, corr="max")
+    hcos.add_battaglia_profile("electron", family="AGN", xmax=50, nxs=30000)
+    Pgn = hcos.get_power("g", "nfw", verbose=False)
+    Pge = hcos.get_power("g", "electron", verbose=False)
+    Pgm = hcos.total_matter_galaxy_power_spectrum(Pgn, Pge)
+    ells = np.linspace(80, 6000, 100)
+    Ckg0 = hcos.C_kg(ells, zs, ks, Pgn, gzs=zgalaxy, lzs=zsource)
+    Ckg = hcos.C_kg(ells, zs, ks, Pgm, gzs=zgalaxy, lzs=zsource)
+    Pnn = hcos.get_power("nfw", verbose=False)
+    Pne = hcos.get_power("nfw", "electron", verbose=False)
+    Pee = hcos.get_power("electron", "electron", verbose=False)
+    Pmm = hcos.total_matter_power_spectrum(Pnn, Pne, Pee)
+    Ckk0 = hcos.C_kk(ells, zs, ks, Pnn, lzs1=zsource, lzs2=zsource)
+    Ckk = hcos.C_kk(ells, zs, ks, Pmm, lzs1=zsource, lzs2=zsource)
+
+    p = merged_params()
+    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+    ci = hmref.CosmoInputs(h=hcos.h, omm0=hcos.omm0, ombh2=p["ombh2"], rho_crit_0=float(hcos.rho_critical_z(0.0)),
+                           rho_crit_zs=hcos.rho_critical_z(zs), Pzk=hcos.Pzk, sPzk=hcos.sPzk, ks_sigma2=ksig,
+                           h_of_z_zs=hcos.h_of_z(zs))
+    o = hmref.RefHaloModel(ci, zs, ks, ms, p)
+    o.add_hod("g", ngal=ngal + zs * 0.0)
+    assert np.allclose(hcos.hods["g"]["log10mthresh"], o.hods["g"]["log10mthresh"], rtol=1e-13)
+    assert np.allclose(hcos.hods["g"]["bg"], o.hods["g"]["bg"], rtol=1e-9)
+    o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], 30000, 50)
+    assert np.max(np.abs(hcos.uk_profiles["electron"] - o.uk_profiles["electron"])) < 1e-12
+    fc = p["omch2"] / (p["omch2"] + p["ombh2"])
+    fb = 1.0 - fc
+    oPgn, oPge = o.get_power("g", "nfw"), o.get_power("g", "electron")
+    oPnn, oPne, oPee = o.get_power("nfw"), o.get_power("nfw", "electron"), o.get_power("electron")
+    oPgm = fc * oPgn + fb * oPge
+    oPmm = fc ** 2 * oPnn + 2 * fc * fb * oPne + fb ** 2 * oPee
+    for got, want in ((Pgn, oPgn), (Pge, oPge), (Pgm, oPgm), (Pnn, oPnn), (Pne, oPne), (Pee, oPee), (Pmm, oPmm)):
+        ok, w = power_close(got, want)
+        assert ok, w
+    H0, chis, hz = hcos.h_of_z(0.0), hcos.comoving_radial_distance(zs), hcos.h_of_z(zs)
+    chig, hg = hcos.comoving_radial_distance(np.array([zgalaxy])), hcos.h_of_z(np.array([zgalaxy]))
+    chistar = hcos.comoving_radial_distance(np.array([zsource]))
+    wg = hmref.lensing_window(np.array([zgalaxy]), zsource, H0, hg, chig, chistar, hcos.omm0)
+    wz = hmref.lensing_window(zs, zsource, H0, hz, chis, chistar, hcos.omm0)
+    oCkg0 = hmref.limber_integral(ells, zs, ks, oPgn, zgalaxy, wg, 1.0, hg, chig)
+    oCkg = hmref.limber_integral(ells, zs, ks, oPgm, zgalaxy, wg, 1.0, hg, chig)
+    oCkk0 = hmref.limber_integral(ells, zs, ks, oPnn, zs, wz, wz, hz, chis)
+    oCkk = hmref.limber_integral(ells, zs, ks, oPmm, zs, wz, wz, hz, chis)
+    for got, want in ((Ckg0, oCkg0), (Ckg, oCkg), (Ckk0, oCkk0), (Ckk, oCkk)):
+        assert np.allclose(got, want, rtol=1e-8, atol=0)
+    # the example's plotted quantities: baryonic feedback suppresses small-scale lensing by a few per cent
+    assert np.all(np.abs(Ckg / Ckg0 - 1) < 0.2) and np.all(np.abs(Ckk / Ckk0 - 1) < 0.2)
+    assert (Ckk / Ckk0)[-1] < 1.0
