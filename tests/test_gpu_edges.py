@@ -256,3 +256,24 @@ def test_lensing_baryons_example_sequence():
     # the example's plotted quantities: baryonic feedback suppresses small-scale lensing by a few per cent
     assert np.all(np.abs(Ckg / Ckg0 - 1) < 0.2) and np.all(np.abs(Ckk / Ckk0 - 1) < 0.2)
     assert (Ckk / Ckk0)[-1] < 1.0
+
+
+def test_numeric_nfw_constructor_default_length():
+    """bin/test_generic_fft.py: HaloModel(..., nfw_numeric=True) transforms the NFW profile with the
+    default nxs=40000 / xmax=200 (hmvec/params.py:59-60; rocFFT route, 20000 complex points per row)
+    and must agree with the analytic profile at the level of the reference's FFT conventions."""
+    import hmvec_amd as hm
+    from oracle import hmref
+    zs = np.array([3.0])
+    ms = np.geomspace(2e10, 1e17, 50)
+    ks = np.geomspace(1e-4, 100, 301)
+    num = hm.HaloModel(zs, ks, ms=ms, nfw_numeric=True, accuracy="low", engine="analytic")
+    ana = hm.HaloModel(zs, ks, ms=ms, nfw_numeric=False, accuracy="low", engine="analytic")
+    un, ua = num.uk_profiles["nfw"], ana.uk_profiles["nfw"]
+    cs, rss = ana.concentration(), ana._d_rvir.numpy() / ana.concentration()
+    want = hmref.profile_fft(lambda x: 1.0 / x / (1.0 + x) ** 2.0, cs, rss, zs, ks, 200, 40000)
+    assert np.max(np.abs(un - want)) < 1e-12
+    sel = ks < 5.0
+    assert np.max(np.abs(un[..., sel] - ua[..., sel])) < 2e-2          # the step/phase quirks of fft_integral
+    p1n, p1a = num.get_power_1halo("nfw"), ana.get_power_1halo("nfw")
+    assert np.allclose(p1n[:, sel], p1a[:, sel], rtol=5e-2)
