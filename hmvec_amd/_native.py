@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 1
+ABI_VERSION = 2
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -37,7 +37,9 @@ class Tracer(C.Structure):
     _fields_ = [("kind", C.c_int), ("d_prof", C.c_void_p), ("d_cprof", C.c_void_p),
                 ("d_Nc", C.c_void_p), ("d_Ns", C.c_void_p), ("d_NcNs", C.c_void_p),
                 ("d_NsNsm1", C.c_void_p), ("d_ngal", C.c_void_p),
-                ("d_bias_override", C.c_void_p)]
+                ("d_bias_override", C.c_void_p),
+                ("d_prof_nconst", C.c_void_p), ("d_prof_cconst", C.c_void_p),
+                ("d_cprof_nconst", C.c_void_p), ("d_cprof_cconst", C.c_void_p)]
 
 
 MF_SHETH_TORMEN, MF_TINKER10 = 0, 1
@@ -73,7 +75,7 @@ SIGNATURES = {
     "hmg_profile_rows_from_mvir": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _D, _P, _P, C.POINTER(_D * 9), _D, _D,
                                    _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hmg_profile_fft": [_P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D, _D,
-                        _P, _P, _P, _P, _I, _P, _P],
+                        _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "hmg_hod": [_P, _I, _I, C.POINTER(HodParams), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hmg_power": [_P, _I, _I, _I, C.POINTER(Tracer), C.POINTER(Tracer), _P, _P, _P, _P, _P, _P,
                   _D, _D, _P, _P],

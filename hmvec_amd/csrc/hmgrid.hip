@@ -693,7 +693,9 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
                                                      const double* __restrict__ zs,
                                                      const double* __restrict__ ks,
                                                      const double* __restrict__ post,
-                                                     double* __restrict__ out) {
+                                                     double* __restrict__ out,
+                                                     double* __restrict__ nconst,
+                                                     double* __restrict__ cconst) {
 #pragma clang fp contract(off)
     extern __shared__ double u[];  // u[j-1] for j = 1..nh
     const int lrow = blockIdx.x, row = row0 + lrow;
@@ -715,6 +717,16 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
     const double k_lo = kout(1), k_hi = kout(nh);
     const double inv_dk = 1.0 / k_lo;  // kts[j] = j*kts[1] up to rounding
     double* dst = out + (size_t)row * nk;
+    if (nconst && threadIdx.x == 0) {
+        int lo = 0, hi = nk;              // first i with !(ks[i] < k_lo); ks ascending
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ks[mid] < k_lo) lo = mid + 1; else hi = mid;
+        }
+        nconst[row] = (double)lo;
+        const double v1 = U(1);
+        cconst[row] = post ? v1 * pf : v1;
+    }
     for (int i = threadIdx.x; i < nk; i += blockDim.x) {
         const double k = ks[i];
         double val;
@@ -761,6 +773,7 @@ struct FusedArgs {
     double amp_c, xc_c, alpha_c, expo_c, gamma, step;
     const double *cmax, *rss, *zs, *ks, *post;
     double* out;
+    double *nconst, *cconst;   // optional constant-prefix hint per row
 };
 
 // amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two
@@ -890,6 +903,15 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     const double k_lo = A.kts[1] * isc, k_hi = A.kts[M] * isc;
     const double inv_dk = 1.0 / k_lo;
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
+    if (A.nconst && threadIdx.x == 0) {
+        int lo = 0, hi = A.nk;            // first i with !(ks[i] < k_lo); ks ascending
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (A.ks[mid] < k_lo) lo = mid + 1; else hi = mid;
+        }
+        A.nconst[row] = (double)lo;
+        A.cconst[row] = u[0] * pf;
+    }
     for (int i = threadIdx.x; i < A.nk; i += NT) {
         const double k = A.ks[i];
         double val;
@@ -1137,6 +1159,9 @@ template <> struct VecT<2> { using type = double2; };
 template <int V> __device__ __forceinline__ double vget(const typename VecT<V>::type& v, int i);
 template <> __device__ __forceinline__ double vget<1>(const double& v, int) { return v; }
 template <> __device__ __forceinline__ double vget<2>(const double2& v, int i) { return i ? v.y : v.x; }
+template <int V> __device__ __forceinline__ typename VecT<V>::type vsplat(double x);
+template <> __device__ __forceinline__ double vsplat<1>(double x) { return x; }
+template <> __device__ __forceinline__ double2 vsplat<2>(double x) { return make_double2(x, x); }
 
 
 // grid (ceil(nk/(64 V)), nz); block 64*MS threads: lane -> V consecutive k, wave -> an
@@ -1293,6 +1318,8 @@ __global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep 
 
 struct BatchArgs {
     const double* tens[PW_MAXT];
+    const double* nconst[PW_MAXT];   // constant-prefix hint of tensor i ([nz][nm]) or nullptr
+    const double* cconst[PW_MAXT];
     const double* coef;
     const double* sidep;             // [nz][nblk][NTR][2] partial {B, C}
     const double* ngal[PB_MAXTR];    // HOD tracers: ngal[z] (bias = B/ngal); else nullptr
@@ -1328,6 +1355,13 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
         for (int p = 0; p < NPAIR; ++p) P[p][v] = 0.0;
     }
     const size_t zrow = (size_t)z * A.nm;
+    const int kend = min(A.nk, (int)(blockIdx.x + 1) * 64 * V);   // one past the last k of this tile
+    int nc_cur[NT], nc_nxt[NT];       // prefix lengths of this wave's current / next mass bin
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        nc_cur[i] = A.nconst[i] ? (int)A.nconst[i][zrow + min(wv, A.nm - 1)] : -1;
+        nc_nxt[i] = A.nconst[i] ? (int)A.nconst[i][zrow + min(wv + MS, A.nm - 1)] : -1;
+    }
 #ifndef HMG_PB_UNROLL
 #define HMG_PB_UNROLL 2
 #endif
@@ -1338,8 +1372,20 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
         const size_t off = (zrow + m) * (size_t)A.nk + k0;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            if (live) t[i] = *reinterpret_cast<const vec_t*>(A.tens[i] + off);
-            else t[i] = vec_t{};
+            // rows whose whole k tile lies in the tensor's constant prefix are not read at all: the
+            // (wave-uniform) hint was fetched one iteration ahead, so the decision costs no latency
+            if (nc_cur[i] >= kend) {
+                t[i] = vsplat<V>(A.cconst[i][zrow + m]);
+            } else if (live) {
+                t[i] = *reinterpret_cast<const vec_t*>(A.tens[i] + off);
+            } else {
+                t[i] = vec_t{};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            nc_cur[i] = nc_nxt[i];
+            if (A.nconst[i]) nc_nxt[i] = (int)A.nconst[i][zrow + min(m + 2 * MS, A.nm - 1)];
         }
         const double wn = c[0], wnb = c[1];
 #pragma unroll
@@ -2143,8 +2189,9 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
                     const double* amp, const double* xcs, const double* alpha, const double* expo,
                     double amp_c, double xc_c, double alpha_c, double expo_c, double gamma,
                     const double* cmax, const double* rss, const double* zs, const double* ks,
-                    int do_mass_norm, const double* post, double* out) {
+                    int do_mass_norm, const double* post, double* out, double* nconst, double* cconst) {
     REQUIRE(c && xs && kts && cmax && rss && zs && ks && out, "NULL argument");
+    REQUIRE((nconst == nullptr) == (cconst == nullptr), "pass both hint arrays or neither");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
     REQUIRE(nxs >= 4, "nxs too small");
     const int nh = nxs / 2;  // rfft output length is nh+1
@@ -2161,6 +2208,7 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
             A.amp = amp; A.xc = xcs; A.alpha = alpha; A.expo = expo;
             A.amp_c = amp_c; A.xc_c = xc_c; A.alpha_c = alpha_c; A.expo_c = expo_c; A.gamma = gamma;
             A.step = step; A.cmax = cmax; A.rss = rss; A.zs = zs; A.ks = ks; A.post = post; A.out = out;
+            A.nconst = nconst; A.cconst = cconst;
             int stop = -1;
             if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
             int rc;
@@ -2203,10 +2251,10 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
         FFT_TRY(rocfft_execute(P->plan, ib, ob, P->info));
         if (stage)
             hipLaunchKernelGGL(interp_kernel<true>, dim3(nr), dim3(256), lds, c->stream, nm, nk, nh, r0, step,
-                               (const double2*)fout, kts, mnorm, rss, zs, ks, post, out);
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, post, out, nconst, cconst);
         else
             hipLaunchKernelGGL(interp_kernel<false>, dim3(nr), dim3(256), 0, c->stream, nm, nk, nh, r0, step,
-                               (const double2*)fout, kts, mnorm, rss, zs, ks, post, out);
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, post, out, nconst, cconst);
         HIP_TRY(hipGetLastError());
     }
     return bracket_close(c, stop);
@@ -2364,7 +2412,17 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     double* sidep = coef + (size_t)nz * nm * stride;
     hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, nblk), dim3(64), 0, c->stream, nm, Q, nzm, bh, ms, wm, coef, sidep);
     HIP_TRY(hipGetLastError());
-    for (int i = 0; i < PW_MAXT; ++i) A.tens[i] = i < Q.nt ? tens[i] : nullptr;
+    for (int i = 0; i < PW_MAXT; ++i) {
+        A.tens[i] = i < Q.nt ? tens[i] : nullptr;
+        A.nconst[i] = A.cconst[i] = nullptr;
+    }
+    for (int t = 0; t < ntr; ++t) {   // constant-prefix hints travel with the tracer that names the tensor
+        const int sp = Q.tr[t].t_prof, sc = Q.tr[t].t_cprof;
+        REQUIRE((tr[t].d_prof_nconst == nullptr) == (tr[t].d_prof_cconst == nullptr) &&
+                (tr[t].d_cprof_nconst == nullptr) == (tr[t].d_cprof_cconst == nullptr), "hint arrays come in pairs");
+        if (sp >= 0 && tr[t].d_prof_nconst && !A.nconst[sp]) { A.nconst[sp] = tr[t].d_prof_nconst; A.cconst[sp] = tr[t].d_prof_cconst; }
+        if (sc >= 0 && tr[t].d_cprof_nconst && !A.nconst[sc]) { A.nconst[sc] = tr[t].d_cprof_nconst; A.cconst[sc] = tr[t].d_cprof_cconst; }
+    }
     for (int t = 0; t < PB_MAXTR; ++t) {
         A.ngal[t] = (t < ntr && tr[t].kind == HMG_TRACER_HOD) ? tr[t].d_ngal : nullptr;
         A.bias_const[t] = (t < ntr && tr[t].kind == HMG_TRACER_MATTER) ? 1.0 : 0.0;
@@ -2526,10 +2584,12 @@ int hmg_profile_fft_table(hmg_ctx* c, int nz, int nm, int nk, int nxs, double st
         FFT_TRY(rocfft_execute(P->plan, ib, ob, P->info));
         if (stage)
             hipLaunchKernelGGL(interp_kernel<true>, dim3(nr), dim3(256), lds, c->stream, nm, nk, nh, r0, step,
-                               (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out);
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out,
+                               (double*)nullptr, (double*)nullptr);
         else
             hipLaunchKernelGGL(interp_kernel<false>, dim3(nr), dim3(256), 0, c->stream, nm, nk, nh, r0, step,
-                               (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out);
+                               (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out,
+                               (double*)nullptr, (double*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     return 0;

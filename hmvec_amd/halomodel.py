@@ -44,13 +44,22 @@ class DeviceDict(MutableMapping):
         self._on_change = on_change or (lambda: None)
         self._dev = {}
         self._host = {}
+        self._hint = {}       # name -> (d_nconst, d_cconst): constant-prefix hint emitted with the tensor
 
     def dev(self, name):
         return self._dev[name]
 
-    def set_dev(self, name, darr):
+    def hint(self, name):
+        """(nconst, cconst) device arrays of a profile produced by hmg_profile_fft, else (None, None)."""
+        return self._hint.get(name, (None, None))
+
+    def set_dev(self, name, darr, hint=None):
         self._dev[name] = darr
         self._host.pop(name, None)
+        if hint is None:
+            self._hint.pop(name, None)      # any other way of (re)defining the tensor drops the hint
+        else:
+            self._hint[name] = hint
         self._on_change()
 
     def __getitem__(self, name):
@@ -67,6 +76,7 @@ class DeviceDict(MutableMapping):
     def __delitem__(self, name):
         del self._dev[name]
         self._host.pop(name, None)
+        self._hint.pop(name, None)
         self._on_change()
 
     def __contains__(self, name):      # Mapping's default would call __getitem__ (a D2H copy)
@@ -410,17 +420,27 @@ class HaloModel(Cosmology):
         return self._dcache[key]
 
     def _profile_fft(self, key, nxs, xmax, rowp, consts, gamma, d_cmax, d_rss, do_mass_norm, d_post=None):
+        """One hmg_profile_fft launch; returns (tensor, hint).  The hint - how many leading target
+        wavenumbers of each row lie below the row's first FFT mode, and the value np.interp's left
+        fill gives them all - lets the batched mass integrals skip those parts of the tensor.  It
+        is only requested when the target k grid is ascending."""
         ctx = self._ctx()
         nz, nm, nk = self._nz, self._nm, self._nk
         d_xs, d_kts, step = self._fft_grids(xmax, nxs)
         out = self._buf(key, (nz, nm, nk))
+        if "ks_ascending" not in self._dcache:
+            self._dcache["ks_ascending"] = (bool(np.all(np.diff(self.ks) > 0))
+                                            and os.environ.get("HMG_NO_HINTS", "0") != "1")   # debugging switch
+        hint = None
+        if self._dcache["ks_ascending"]:
+            hint = (self._buf((key, "nconst"), (nz, nm)), self._buf((key, "cconst"), (nz, nm)))
         amp, xc, alpha, expo = rowp
         ctx.call("hmg_profile_fft", nz, nm, nk, int(nxs), step, d_xs.ptr, d_kts.ptr,
                  nat.ptr(amp), nat.ptr(xc), nat.ptr(alpha), nat.ptr(expo),
                  float(consts[0]), float(consts[1]), float(consts[2]), float(consts[3]), float(gamma),
                  d_cmax.ptr, d_rss.ptr, self._d_zs().ptr, self._d_ks().ptr, int(do_mass_norm),
-                 nat.ptr(d_post), out.ptr)
-        return out
+                 nat.ptr(d_post), out.ptr, nat.ptr(hint[0] if hint else None), nat.ptr(hint[1] if hint else None))
+        return out, hint
 
     def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref):
         ctx = self._ctx()
@@ -472,11 +492,11 @@ class HaloModel(Cosmology):
         self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
         amp, xc, alpha, expo, cmax, rscale, _post = self._battaglia_rowparams(
             key, nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0)
-        out = self._profile_fft(key, nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
-                                cmax, rscale, True)
+        out, hint = self._profile_fft(key, nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
+                                      cmax, rscale, True)
         self._mark(self._EV_TAIL2)
         self._on_lane(0)
-        self.uk_profiles.set_dev(name, out)
+        self.uk_profiles.set_dev(name, out, hint)
 
     def add_battaglia_pres_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
                                    ignore_existing=False):
@@ -511,11 +531,11 @@ class HaloModel(Cosmology):
         self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
         amp, xc, _alpha, expo, cmax, rscale, post = self._battaglia_rowparams(
             key, nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref)
-        out = self._profile_fft(key, nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
-                                cmax, rscale, False, d_post=post)
+        out, hint = self._profile_fft(key, nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
+                                      cmax, rscale, False, d_post=post)
         self._mark(self._EV_TAIL2)
         self._on_lane(0)
-        self.pk_profiles.set_dev(name, out)
+        self.pk_profiles.set_dev(name, out, hint)
 
     def add_nfw_profile(self, name, numeric=False, nxs=None, xmax=None, ignore_existing=False):
         """NFW u(k|m,z): analytic Si/Ci or numeric FFT branch (hmvec/hmvec.py:318-355).
@@ -528,11 +548,12 @@ class HaloModel(Cosmology):
             xmax = self.p["nfw_integral_xmax"]
         ctx = self._ctx()
         nz, nm, nk = self._nz, self._nm, self._nk
+        hint = None
         if numeric:
             # rho = 1/x/(1+x)^2 is the gamma=-1, alpha=1, expo=2 member of the family
             self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
-            out = self._profile_fft(("uk", name), nxs, xmax, (None, None, None, None), (1.0, 1.0, 1.0, 2.0),
-                                    -1.0, self._d_cs, self._d_rs, True)
+            out, hint = self._profile_fft(("uk", name), nxs, xmax, (None, None, None, None), (1.0, 1.0, 1.0, 2.0),
+                                          -1.0, self._d_cs, self._d_rs, True)
             self._mark(self._EV_TAIL2)
         else:
             out = self._buf(("uk", name), (nz, nm, nk))
@@ -541,7 +562,7 @@ class HaloModel(Cosmology):
                      self._d_ks().ptr, out.ptr)
             self._mark(self._EV_TAIL1)
         self._on_lane(0)
-        self.uk_profiles.set_dev(name, out)
+        self.uk_profiles.set_dev(name, out, hint)
         return self.ks, _LazyArray(self.uk_profiles, name)
 
     # ------------------------------------------------------------------ HOD
@@ -642,14 +663,22 @@ class HaloModel(Cosmology):
                 hod = self.hods[name]
                 cn = hod["central_profile"]
                 d = hod.dev
-                t = nat.Tracer(nat.TRACER_HOD, self.uk_profiles.dev(hod["satellite_profile"]).ptr,
+                sn = hod["satellite_profile"]
+                hs = self.uk_profiles.hint(sn)
+                hc = self.uk_profiles.hint(cn) if cn is not None else (None, None)
+                t = nat.Tracer(nat.TRACER_HOD, self.uk_profiles.dev(sn).ptr,
                                None if cn is None else self.uk_profiles.dev(cn).ptr,
-                               d["Nc"].ptr, d["Ns"].ptr, d["NcNs"].ptr, d["NsNsm1"].ptr, d["ngal"].ptr, None)
+                               d["Nc"].ptr, d["Ns"].ptr, d["NcNs"].ptr, d["NsNsm1"].ptr, d["ngal"].ptr, None,
+                               nat.ptr(hs[0]), nat.ptr(hs[1]), nat.ptr(hc[0]), nat.ptr(hc[1]))
                 return t, "h"
             if kind == "m" and name in self.uk_profiles:
-                return nat.Tracer(nat.TRACER_MATTER, self.uk_profiles.dev(name).ptr), "m"
+                hp = self.uk_profiles.hint(name)
+                return nat.Tracer(nat.TRACER_MATTER, self.uk_profiles.dev(name).ptr, None, None, None, None, None,
+                                  None, None, nat.ptr(hp[0]), nat.ptr(hp[1])), "m"
             if kind == "p" and name in self.pk_profiles:
-                return nat.Tracer(nat.TRACER_PRESSURE, self.pk_profiles.dev(name).ptr), "p"
+                hp = self.pk_profiles.hint(name)
+                return nat.Tracer(nat.TRACER_PRESSURE, self.pk_profiles.dev(name).ptr, None, None, None, None, None,
+                                  None, None, nat.ptr(hp[0]), nat.ptr(hp[1])), "p"
         raise ValueError
 
     def _power_launch(self, ta, tb, want1, want2, out1=None, out2=None):
