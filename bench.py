@@ -271,7 +271,11 @@ def main():
                          "frac": gbs["power"] / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "(2*FETCH+WRITE)*1024 bytes per launch)" if traffic else None,
-                         "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"]},
+                         "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"],
+                         "hbm_actual_GBps": (traffic / (kern_ms["power"] * 1e-3) / 1e9) if traffic else None,
+                         "note": "traffic < algorithmic bytes: 62 % of the Battaglia tensor is np.interp's constant "
+                                 "left fill, reported by hmg_profile_fft as a per-row hint and substituted instead of "
+                                 "read (bit-identical results; HMG_NO_HINTS=1 disables)"},
         }
         if pcie is not None:
             out["pcie"] = pcie
