@@ -277,3 +277,48 @@ def test_numeric_nfw_constructor_default_length():
     assert np.max(np.abs(un[..., sel] - ua[..., sel])) < 2e-2          # the step/phase quirks of fft_integral
     p1n, p1a = num.get_power_1halo("nfw"), ana.get_power_1halo("nfw")
     assert np.allclose(p1n[:, sel], p1a[:, sel], rtol=5e-2)
+
+
+def test_constant_prefix_hints_change_nothing(monkeypatch):
+    """hmg_profile_fft's per-row hints (np.interp left-fill region) let hmg_power_batch skip parts of a
+    tensor; the spectra must be bit-identical with and without them, a descending k grid must get no
+    hints, and redefining the tensor by hand must drop them."""
+    import hmvec_amd as hm
+    zs = np.array([0.2, 1.0, 2.5])
+    ms = np.geomspace(1e10, 1e16, 96)
+    ks = np.geomspace(1e-4, 50, 512)
+    pairs = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("nfw", "electron"), ("g", "electron"), ("y", "y"),
+             ("y", "electron")]
+
+    def build(kgrid):
+        h = hm.HaloModel(zs, kgrid, ms=ms, accuracy="low", engine="analytic")
+        h.add_battaglia_profile("electron", nxs=1000, xmax=20)
+        h.add_battaglia_pres_profile("y", nxs=1000, xmax=20)
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, central_profile_name="electron")
+        return h
+
+    h = build(ks)
+    hint = h.uk_profiles.hint("electron")
+    assert hint[0] is not None and h.pk_profiles.hint("y")[0] is not None and h.uk_profiles.hint("nfw")[0] is None
+    n, c = hint[0].numpy(), hint[1].numpy()
+    ue = h.uk_profiles["electron"]
+    assert n.min() >= 0 and n.max() > 128                       # whole 128-k tiles are skippable on this grid
+    for iz, im in ((0, 0), (1, 40), (2, 95)):
+        k = int(n[iz, im])
+        assert np.all(ue[iz, im, :k] == c[iz, im]) and (k == ks.size or ue[iz, im, k] != c[iz, im])
+    with_hints = h.get_power_all(pairs[:5])
+    monkeypatch.setenv("HMG_NO_HINTS", "1")
+    h0 = build(ks)
+    assert h0.uk_profiles.hint("electron")[0] is None
+    without = h0.get_power_all(pairs[:5])
+    for p in pairs[:5]:
+        assert np.array_equal(with_hints[p], without[p]), p
+    monkeypatch.delenv("HMG_NO_HINTS")
+    hd = build(ks[::-1].copy())                                 # descending grid: no prefix notion
+    assert hd.uk_profiles.hint("electron")[0] is None
+    assert np.allclose(hd.get_power("g", "electron")[:, ::-1], with_hints[("g", "electron")], rtol=1e-12, atol=0)
+    h.uk_profiles["electron"] = ue * 2.0                        # redefined by hand: the hint must go
+    assert h.uk_profiles.hint("electron")[0] is None
+    p1_before = build(ks).get_power_1halo("electron")
+    o1, _ = h.power_device_batch([("electron", "electron")])   # batched kernel: the one that uses hints
+    assert np.allclose(o1[0].numpy(), 4.0 * p1_before, rtol=1e-12, atol=0)       # 1-halo is quadratic in u
