@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
                                                      const double* __restrict__ ks,
                                                      const double* __restrict__ post,
                                                      double* __restrict__ out,
-                                                     double* __restrict__ nconst,
+                                                     int* __restrict__ nconst,
                                                      double* __restrict__ cconst) {
 #pragma clang fp contract(off)
     extern __shared__ double u[];  // u[j-1] for j = 1..nh
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
             const int mid = (lo + hi) >> 1;
             if (ks[mid] < k_lo) lo = mid + 1; else hi = mid;
         }
-        nconst[row] = (double)lo;
+        nconst[row] = lo;
         const double v1 = U(1);
         cconst[row] = post ? v1 * pf : v1;
     }
@@ -773,7 +773,8 @@ struct FusedArgs {
     double amp_c, xc_c, alpha_c, expo_c, gamma, step;
     const double *cmax, *rss, *zs, *ks, *post;
     double* out;
-    double *nconst, *cconst;   // optional constant-prefix hint per row
+    int* nconst;               // optional constant-prefix hint per row
+    double* cconst;
 };
 
 // amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
             const int mid = (lo + hi) >> 1;
             if (A.ks[mid] < k_lo) lo = mid + 1; else hi = mid;
         }
-        A.nconst[row] = (double)lo;
+        A.nconst[row] = lo;
         A.cconst[row] = u[0] * pf;
     }
     for (int i = threadIdx.x; i < A.nk; i += NT) {
@@ -1318,7 +1319,7 @@ __global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep 
 
 struct BatchArgs {
     const double* tens[PW_MAXT];
-    const double* nconst[PW_MAXT];   // constant-prefix hint of tensor i ([nz][nm]) or nullptr
+    const int* nconst[PW_MAXT];      // constant-prefix hint of tensor i ([nz][nm]) or nullptr
     const double* cconst[PW_MAXT];
     const double* coef;
     const double* sidep;             // [nz][nblk][NTR][2] partial {B, C}
@@ -1357,10 +1358,13 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
     const size_t zrow = (size_t)z * A.nm;
     const int kend = min(A.nk, (int)(blockIdx.x + 1) * 64 * V);   // one past the last k of this tile
     int nc_cur[NT], nc_nxt[NT];       // prefix lengths of this wave's current / next mass bin
+    double cc_cur[NT], cc_nxt[NT];    // and the prefix values
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        nc_cur[i] = A.nconst[i] ? (int)A.nconst[i][zrow + min(wv, A.nm - 1)] : -1;
-        nc_nxt[i] = A.nconst[i] ? (int)A.nconst[i][zrow + min(wv + MS, A.nm - 1)] : -1;
+        nc_cur[i] = A.nconst[i] ? A.nconst[i][zrow + min(wv, A.nm - 1)] : -1;
+        nc_nxt[i] = A.nconst[i] ? A.nconst[i][zrow + min(wv + MS, A.nm - 1)] : -1;
+        cc_cur[i] = A.nconst[i] ? A.cconst[i][zrow + min(wv, A.nm - 1)] : 0.0;
+        cc_nxt[i] = A.nconst[i] ? A.cconst[i][zrow + min(wv + MS, A.nm - 1)] : 0.0;
     }
 #ifndef HMG_PB_UNROLL
 #define HMG_PB_UNROLL 2
@@ -1375,7 +1379,7 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
             // rows whose whole k tile lies in the tensor's constant prefix are not read at all: the
             // (wave-uniform) hint was fetched one iteration ahead, so the decision costs no latency
             if (nc_cur[i] >= kend) {
-                t[i] = vsplat<V>(A.cconst[i][zrow + m]);
+                t[i] = vsplat<V>(cc_cur[i]);
             } else if (live) {
                 t[i] = *reinterpret_cast<const vec_t*>(A.tens[i] + off);
             } else {
@@ -1385,7 +1389,11 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             nc_cur[i] = nc_nxt[i];
-            if (A.nconst[i]) nc_nxt[i] = (int)A.nconst[i][zrow + min(m + 2 * MS, A.nm - 1)];
+            cc_cur[i] = cc_nxt[i];
+            if (A.nconst[i]) {
+                nc_nxt[i] = A.nconst[i][zrow + min(m + 2 * MS, A.nm - 1)];
+                cc_nxt[i] = A.cconst[i][zrow + min(m + 2 * MS, A.nm - 1)];
+            }
         }
         const double wn = c[0], wnb = c[1];
 #pragma unroll
@@ -2189,7 +2197,7 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
                     const double* amp, const double* xcs, const double* alpha, const double* expo,
                     double amp_c, double xc_c, double alpha_c, double expo_c, double gamma,
                     const double* cmax, const double* rss, const double* zs, const double* ks,
-                    int do_mass_norm, const double* post, double* out, double* nconst, double* cconst) {
+                    int do_mass_norm, const double* post, double* out, int* nconst, double* cconst) {
     REQUIRE(c && xs && kts && cmax && rss && zs && ks && out, "NULL argument");
     REQUIRE((nconst == nullptr) == (cconst == nullptr), "pass both hint arrays or neither");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
@@ -2414,7 +2422,8 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < PW_MAXT; ++i) {
         A.tens[i] = i < Q.nt ? tens[i] : nullptr;
-        A.nconst[i] = A.cconst[i] = nullptr;
+        A.nconst[i] = nullptr;
+        A.cconst[i] = nullptr;
     }
     for (int t = 0; t < ntr; ++t) {   // constant-prefix hints travel with the tracer that names the tensor
         const int sp = Q.tr[t].t_prof, sc = Q.tr[t].t_cprof;
@@ -2585,11 +2594,11 @@ int hmg_profile_fft_table(hmg_ctx* c, int nz, int nm, int nk, int nxs, double st
         if (stage)
             hipLaunchKernelGGL(interp_kernel<true>, dim3(nr), dim3(256), lds, c->stream, nm, nk, nh, r0, step,
                                (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out,
-                               (double*)nullptr, (double*)nullptr);
+                               (int*)nullptr, (double*)nullptr);
         else
             hipLaunchKernelGGL(interp_kernel<false>, dim3(nr), dim3(256), 0, c->stream, nm, nk, nh, r0, step,
                                (const double2*)fout, kts, mnorm, rss, zs, ks, (const double*)nullptr, out,
-                               (double*)nullptr, (double*)nullptr);
+                               (int*)nullptr, (double*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     return 0;

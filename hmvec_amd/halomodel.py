@@ -433,7 +433,8 @@ class HaloModel(Cosmology):
                                             and os.environ.get("HMG_NO_HINTS", "0") != "1")   # debugging switch
         hint = None
         if self._dcache["ks_ascending"]:
-            hint = (self._buf((key, "nconst"), (nz, nm)), self._buf((key, "cconst"), (nz, nm)))
+            # nconst is an int32 array: allocated as (nz*nm+1)//2 doubles, viewed as integers on read
+            hint = (self._buf((key, "nconst"), ((nz * nm + 1) // 2,)), self._buf((key, "cconst"), (nz, nm)))
         amp, xc, alpha, expo = rowp
         ctx.call("hmg_profile_fft", nz, nm, nk, int(nxs), step, d_xs.ptr, d_kts.ptr,
                  nat.ptr(amp), nat.ptr(xc), nat.ptr(alpha), nat.ptr(expo),

@@ -171,7 +171,7 @@ int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_st
                     const double* d_zs, const double* d_ks, int do_mass_norm,
                     const double* d_post /*[nz][nm] or NULL*/,
                     double* d_out /*[nz][nm][nk]*/,
-                    double* d_nconst /*[nz][nm] or NULL*/, double* d_cconst /*[nz][nm] or NULL*/);
+                    int* d_nconst /*[nz][nm] or NULL*/, double* d_cconst /*[nz][nm] or NULL*/);
 /* d_nconst / d_cconst (both or neither): constant-prefix hint of every output row for hmg_tracer -
  * the number of leading target wavenumbers below the row's first FFT mode and the value they all
  * receive.  Only meaningful when d_ks is ascending (the caller's responsibility).               */
@@ -205,12 +205,12 @@ typedef struct {
     const double *d_Nc, *d_Ns, *d_NcNs, *d_NsNsm1, *d_ngal;   /* HOD only */
     const double* d_bias_override;  /* [nz] replaces b (b1_in/b2_in), or NULL */
     /* Optional constant-prefix hints for the two profile tensors (NULL = none): the first
-     * (int)nconst[z][m] entries of row (z,m) all equal cconst[z][m].  hmg_profile_fft can emit them
+     * nconst[z][m] entries of row (z,m) all equal cconst[z][m].  hmg_profile_fft can emit them
      * (np.interp's left fill, hmvec/fft.py:107: every target k below the first FFT mode gets the
      * same value - 63 % of a Battaglia tensor at Config 3).  hmg_power_batch then substitutes the
      * constant instead of reading those parts of the tensor; results are bit-identical.         */
-    const double *d_prof_nconst, *d_prof_cconst;     /* [nz][nm] each */
-    const double *d_cprof_nconst, *d_cprof_cconst;
+    const int*    d_prof_nconst;   const double* d_prof_cconst;      /* [nz][nm] each */
+    const int*    d_cprof_nconst;  const double* d_cprof_cconst;
 } hmg_tracer;
 int hmg_power(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_tracer* h_a, const hmg_tracer* h_b,
               const double* d_nzm, const double* d_bh, const double* d_ms, const double* d_wm,

@@ -300,7 +300,7 @@ def test_constant_prefix_hints_change_nothing(monkeypatch):
     h = build(ks)
     hint = h.uk_profiles.hint("electron")
     assert hint[0] is not None and h.pk_profiles.hint("y")[0] is not None and h.uk_profiles.hint("nfw")[0] is None
-    n, c = hint[0].numpy(), hint[1].numpy()
+    n, c = hint[0].numpy().view(np.int32)[:zs.size * ms.size].reshape(zs.size, ms.size), hint[1].numpy()
     ue = h.uk_profiles["electron"]
     assert n.min() >= 0 and n.max() > 128                       # whole 128-k tiles are skippable on this grid
     for iz, im in ((0, 0), (1, 40), (2, 95)):
