@@ -1163,6 +1163,14 @@ template <> __device__ __forceinline__ double vget<2>(const double2& v, int i) {
 template <int V> __device__ __forceinline__ typename VecT<V>::type vsplat(double x);
 template <> __device__ __forceinline__ double vsplat<1>(double x) { return x; }
 template <> __device__ __forceinline__ double2 vsplat<2>(double x) { return make_double2(x, x); }
+// streamed-once tensor data: non-temporal load (does not displace the coefficient rows and hints in the caches)
+template <int V> __device__ __forceinline__ typename VecT<V>::type vload_nt(const double* p);
+template <> __device__ __forceinline__ double vload_nt<1>(const double* p) { return __builtin_nontemporal_load(p); }
+template <> __device__ __forceinline__ double2 vload_nt<2>(const double* p) {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p));
+    return make_double2(v.x, v.y);
+}
 
 
 // grid (ceil(nk/(64 V)), nz); block 64*MS threads: lane -> V consecutive k, wave -> an
@@ -1381,7 +1389,7 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
             if (nc_cur[i] >= kend) {
                 t[i] = vsplat<V>(cc_cur[i]);
             } else if (live) {
-                t[i] = *reinterpret_cast<const vec_t*>(A.tens[i] + off);
+                t[i] = vload_nt<V>(A.tens[i] + off);
             } else {
                 t[i] = vec_t{};
             }
