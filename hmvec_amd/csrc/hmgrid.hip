@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
             double u = fma_svs(a[NFW_NS - 1], z, a[NFW_NS - 2]);
 #pragma unroll
             for (int n = NFW_NS - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
-            dst[k] = u;
+            __builtin_nontemporal_store(u, &dst[k]);
             continue;
         }
         if (use_series && xc <= NFW_X2) {
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
             double u = fma_svs(a[NFW_NS2 - 1], z, a[NFW_NS2 - 2]);
 #pragma unroll
             for (int n = NFW_NS2 - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
-            dst[k] = u;
+            __builtin_nontemporal_store(u, &dst[k]);
             continue;
         }
         if (x > 4.0 && xc < 1.0e9) {
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
             sici_aux<false>(T, x, zx, f1, g1);
             sici_aux<true>(T, xc, zc, f2, g2);
             sincos_fast(c * x, sd, cd);
-            dst[k] = (g1 + (f2 - xc * zc) * sd - g2 * cd) * inv_mc;
+            __builtin_nontemporal_store((g1 + (f2 - xc * zc) * sd - g2 * cd) * inv_mc, &dst[k]);
             continue;
         }
         double s1, c1, s2, c2;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
         if (sm1) dci += sm2 ? ln_opc : -(EULER_GAMMA + log(x));
         const double scx = s2 * c1 - c2 * s1;  // sin(c x) = sin((1+c)x - x)
         // sin(cx)/((1+c)x) = scx * xc / xc^2
-        dst[k] = (s1 * (si2 - si1) - scx * (xc * zc) + c1 * dci) * inv_mc;
+        __builtin_nontemporal_store((s1 * (si2 - si1) - scx * (xc * zc) + c1 * dci) * inv_mc, &dst[k]);
     }
 }
 
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
             const double y0 = u[j - 1], y1 = u[j];
             val = (x0 == k) ? y0 : fma((y1 - y0) * rcp_fast(x1 - x0), k - x0, y0);
         }
-        dst[i] = val * pf;
+        __builtin_nontemporal_store(val * pf, &dst[i]);
     }
 }
 
