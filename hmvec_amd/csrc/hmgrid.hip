@@ -1365,44 +1365,28 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
     }
     const size_t zrow = (size_t)z * A.nm;
     const int kend = min(A.nk, (int)(blockIdx.x + 1) * 64 * V);   // one past the last k of this tile
-    int nc_cur[NT], nc_nxt[NT];       // prefix lengths of this wave's current / next mass bin
-    double cc_cur[NT], cc_nxt[NT];    // and the prefix values
+    const size_t kofs = live ? (size_t)k0 : 0;   // dead lanes re-read column 0 (their sums are never stored)
+    // constant-prefix hint of mass bin m: how many leading k of the row equal `val`
+    struct Hint { int n[NT]; double val[NT]; };
+    auto load_hint = [&](Hint& h, int m) {
+        const size_t r = zrow + min(m, A.nm - 1);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        nc_cur[i] = A.nconst[i] ? A.nconst[i][zrow + min(wv, A.nm - 1)] : -1;
-        nc_nxt[i] = A.nconst[i] ? A.nconst[i][zrow + min(wv + MS, A.nm - 1)] : -1;
-        cc_cur[i] = A.nconst[i] ? A.cconst[i][zrow + min(wv, A.nm - 1)] : 0.0;
-        cc_nxt[i] = A.nconst[i] ? A.cconst[i][zrow + min(wv + MS, A.nm - 1)] : 0.0;
-    }
-#ifndef HMG_PB_UNROLL
-#define HMG_PB_UNROLL 2
-#endif
-#pragma unroll HMG_PB_UNROLL
-    for (int m = wv; m < A.nm; m += MS) {
+        for (int i = 0; i < NT; ++i) {
+            h.n[i] = A.nconst[i] ? A.nconst[i][r] : -1;
+            h.val[i] = A.nconst[i] ? A.cconst[i][r] : 0.0;
+        }
+    };
+    // rows whose whole k tile lies in a tensor's constant prefix are not read at all
+    auto fetch = [&](vec_t (&dst)[NT], int m, const Hint& h) {
+        const size_t off = (zrow + min(m, A.nm - 1)) * (size_t)A.nk + kofs;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (h.n[i] >= kend) dst[i] = vsplat<V>(h.val[i]);
+            else dst[i] = vload_nt<V>(A.tens[i] + off);
+        }
+    };
+    auto accumulate = [&](const vec_t (&t)[NT], int m) {
         const double* __restrict__ c = A.coef + (zrow + m) * (size_t)STRIDE;
-        vec_t t[NT];
-        const size_t off = (zrow + m) * (size_t)A.nk + k0;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            // rows whose whole k tile lies in the tensor's constant prefix are not read at all: the
-            // (wave-uniform) hint was fetched one iteration ahead, so the decision costs no latency
-            if (nc_cur[i] >= kend) {
-                t[i] = vsplat<V>(cc_cur[i]);
-            } else if (live) {
-                t[i] = vload_nt<V>(A.tens[i] + off);
-            } else {
-                t[i] = vec_t{};
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            nc_cur[i] = nc_nxt[i];
-            cc_cur[i] = cc_nxt[i];
-            if (A.nconst[i]) {
-                nc_nxt[i] = A.nconst[i][zrow + min(m + 2 * MS, A.nm - 1)];
-                cc_nxt[i] = A.cconst[i][zrow + min(m + 2 * MS, A.nm - 1)];
-            }
-        }
         const double wn = c[0], wnb = c[1];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -1433,7 +1417,31 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
                 }
             }
         }
+    };
+    // Two-stage software pipeline over this wavefront's mass bins (m, m+MS, ...): the loads of the
+    // next bin are in flight while the current one is consumed, and the hints run one bin further
+    // ahead so that a fetch never waits for its own decision.  The scheduling barriers keep hipcc
+    // from sinking the early loads back down to their first use.
+    int m = wv;
+    vec_t ta[NT], tb[NT];
+    Hint ha, hb;
+    load_hint(ha, m);
+    load_hint(hb, m + MS);
+    fetch(ta, m, ha);
+#pragma unroll 1
+    for (; m + MS < A.nm; m += 2 * MS) {
+        fetch(tb, m + MS, hb);
+        load_hint(ha, m + 2 * MS);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(ta, m);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(ta, m + 2 * MS, ha);
+        load_hint(hb, m + 3 * MS);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(tb, m + MS);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (m < A.nm) accumulate(ta, m);
     // cross-wave reduction through LDS, one accumulator at a time (keeps LDS at MS*V*512 B)
     auto reduce = [&](double (&acc)[V]) {
         __syncthreads();
