@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(1024) void power_kernel(PowerArgs A) {
         const size_t off = (zrow + m) * (size_t)A.nk + k0;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            if (live) t[i] = *reinterpret_cast<const vec_t*>(A.tens[i] + off);
+            if (live) t[i] = vload_nt<V>(A.tens[i] + off);
             else t[i] = vec_t{};
         }
 #pragma unroll
