@@ -79,8 +79,8 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)     # 0.8 ms each: clocks and caches settle after ~10
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nz", type=int, default=32)
     ap.add_argument("--nm", type=int, default=512)
     ap.add_argument("--nk", type=int, default=4096)
