@@ -111,14 +111,20 @@ class ShardedSpectra:
     `model` is a HaloModel built on the slab redshifts; `comm` provides allgather_rows.
     """
 
-    def __init__(self, model, comm, nz_total, pairs):
+    _EV_SPECTRA, _EV_GATHERED = 8, 9      # event slots (HaloModel uses 0-3, bench.py 16 and up)
+    _COMM_LANE = 3
+
+    def __init__(self, model, comm, nz_total, pairs, force_gather=False):
+        """force_gather: take the gather path (separate `full` buffers, communication lane) even with a
+        single rank - used to exercise it on one GPU."""
         self.model, self.comm, self.pairs = model, comm, list(pairs)
+        self._gather = comm.world > 1 or force_gather
         ctx = model._ctx()
         nzl, nk = model.zs.size, model.ks.size
         if nzl * comm.world != nz_total:
             raise ValueError("slab size x ranks != nz_total")
         self.local = [ctx.empty((nzl, nk)) for _ in range(2 * len(self.pairs))]
-        if comm.world > 1:
+        if self._gather:
             self.full = [ctx.empty((nz_total, nk)) for _ in range(2 * len(self.pairs))]
         else:
             self.full = self.local
@@ -127,15 +133,28 @@ class ShardedSpectra:
         """Launch all spectra + the gather; asynchronous (no host sync).  `bracket` = (s0, s1)
         event slots around the mass-integral kernel (batched mode) for bench.py."""
         m = self.model
+        ctx = m._ctx()
+        gather = self._gather
+        if gather:
+            # the previous call's gather (on its own lane) must have finished reading `local`
+            ctx.wait(self._EV_GATHERED)
         if batched:
             if bracket is not None:
-                m._ctx().call("hmg_bracket_next", nat.KERNEL_POWER, bracket[0], bracket[1])
+                ctx.call("hmg_bracket_next", nat.KERNEL_POWER, bracket[0], bracket[1])
             m.power_device_batch(self.pairs, self.local[0::2], self.local[1::2])
         else:
             for i, (a, b) in enumerate(self.pairs):
                 m.power_device(a, b, out1=self.local[2 * i], out2=self.local[2 * i + 1])
-        if self.comm.world > 1:
+        if gather:
+            # The collective runs on the communication lane behind an event, so that the next pass of
+            # the path (which does not touch `full`, and `local` only after the wait above) overlaps it:
+            # over xGMI the all-gather of a 0.2 ms slab step would otherwise be a visible fraction of it.
+            ctx.record(self._EV_SPECTRA)
+            ctx.lane(self._COMM_LANE)
+            ctx.wait(self._EV_SPECTRA)
             self.comm.allgather_rows(self.local, self.full)
+            ctx.record(self._EV_GATHERED)
+            ctx.lane(0)
 
     def results(self):
         """{(a,b): (P1h, P2h)} as numpy (nz_total, nk) arrays; blocks."""

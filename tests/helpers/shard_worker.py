@@ -32,6 +32,16 @@ class HostCtx:
     def empty(self, shape):
         return HostArray(shape)
 
+    # stream/event plumbing of the device context: nothing to order on the host
+    def wait(self, slot):
+        pass
+
+    def record(self, slot):
+        pass
+
+    def lane(self, i):
+        pass
+
 
 class OracleEngine:
     """Looks like the slice of HaloModel that ShardedSpectra touches."""
