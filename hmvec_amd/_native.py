@@ -107,6 +107,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU "
             "fallback. Run `make -C hmvec_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+    # The host driver of this platform only supports dmabuf IPC; RCCL's peer-to-peer set-up fails with
+    # hipIpcGetMemHandle "invalid argument" otherwise.  Must be in the environment before the HSA
+    # runtime initialises, i.e. before the library (and with it libamdhip64) is loaded.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
