@@ -7,13 +7,17 @@ Workload (configs[2], "Config 3"): zs=linspace(0.01,3,32), ms=geomspace(2e10,1e1
 ks=geomspace(1e-4,100,4096); analytic NFW + Battaglia AGN electron profile (nxs=5000,
 xmax=20) + HOD 'g' (mthresh=10^10.5); all six auto/cross spectra, 1-halo + 2-halo.
 One STEP = one full pass of the path: sigma^2 -> n(z,m), b(z,m) -> c, rvir -> NFW u(k) ->
-mass conversion -> Battaglia rows -> integrand/rocFFT/interpolation -> HOD -> 6 fused
-mass-integral launches (-> RCCL all-gather of the z-slabs when N>1).  Inputs (grids, P(k))
-are resident in HBM before the timed region; results stay in HBM.
+mass conversion -> Battaglia rows -> integrand/FFT/interpolation -> HOD -> fused mass
+integrals of the six spectra (-> RCCL all-gather of the z-slabs when N>1).  Inputs (grids,
+P(k)) are resident in HBM before the timed region; results stay in HBM.  The launches of a
+step are captured once as a HIP graph and replayed (--no-graph issues them one by one).
 
-N>1: launched one process per GPU by torch.distributed.run (env RANK/LOCAL_RANK/WORLD_SIZE);
-the SAME grid is partitioned in contiguous z-slabs (strong scaling), gathered with one RCCL
-group call.  The host side uses no torch: rendezvous is a file, barriers/gathers are RCCL
+N>1: one process per GPU.  Started as the driver starts it for N=1 (`python bench.py --gpus N`,
+no WORLD_SIZE in the environment) this script spawns the N ranks itself - fresh child
+processes from a parent that never touches the GPU - and relays rank 0's JSON line; under
+`torch.distributed.run` (RANK/LOCAL_RANK/WORLD_SIZE set) it is one of the ranks.  The SAME
+grid is partitioned in contiguous z-slabs (strong scaling) and gathered with one RCCL group
+call per step.  The host side uses no torch: rendezvous is a file, barriers/gathers are RCCL
 calls inside libhmgrid.
 
 Prints ONE JSON line on rank 0.
@@ -21,6 +25,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,9 +36,11 @@ sys.path.insert(0, REPO)
 
 PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"),
          ("nfw", "electron"), ("g", "nfw"), ("g", "electron")]
-# distinct [z][m][k] tensors each pair streams: g uses the nfw profile as satellite
-PAIR_TENSORS = [1, 1, 1, 2, 1, 2]
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_VALU_CYCLES = 4      # a wave64 fp64 VALU instruction occupies its SIMD-32 for 4 cycles
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
+PROFILE_DIR = os.path.join(REPO, "profiles", "r02")
+BRACKET_EVERY = 4         # kernel-level HIP events ride on every 4th timed step
 
 
 def workload(nz=32, nm=512, nk=4096):
@@ -43,177 +50,419 @@ def workload(nz=32, nm=512, nk=4096):
     return zs, ms, ks
 
 
-def power_alg_bytes(nz, nm, nk, d):
-    """Algorithmic HBM bytes of one fused 1h+2h launch (SURVEY §8d W_mass)."""
-    return 8 * nz * nm * nk * d + 8 * nz * nm * 6 + 8 * nz * nk * 3
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no rank environment
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """Start one fresh process per GPU with RANK/LOCAL_RANK/WORLD_SIZE set, relay rank 0's stdout.
+    The parent makes no GPU call (it does not even import the package), so nothing is re-executed
+    from a process that has initialised the device."""
+    import socket
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run"]
+    envs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HMG_LAUNCH_TAG=f"{port}_{os.getpid()}")
+        # dmabuf IPC is the only mode the host driver of this pool supports; RCCL's peer set-up needs it
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        envs.append(env)
+    if args.dry_run:
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HMG_LAUNCH_TAG",
+                "HSA_ENABLE_IPC_MODE_LEGACY")
+        print(json.dumps({"dry_run": True, "n_ranks": n, "cmd": cmd,
+                          "rank_env": [{k: e[k] for k in keys} for e in envs]}))
+        return 0
+    procs = [subprocess.Popen(cmd, env=envs[r], stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL)
+             for r in range(n)]
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write(f"bench.py launcher: rank exit codes {rcs}\n")
+        return 1
+    return 0
 
 
-def cpu_baseline(zs, ms, ks, nz_sample, nxs):
-    """Time the CPU oracle (numpy restatement of the reference, pinned by tests/golden) on a
-    z-subsample of the same workload, on this box's host cores.  numpy elementwise ops,
-    trapz, pocketfft and interp are single-threaded: 1 core effective."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (BASELINE.md section 4)
+# ------------------------------------------------------------------------------------------------
+def _cpu_inputs(zs, ks, p):
     import hmvec_amd as hm
-    from hmvec_amd.params import battaglia_defaults, default_params
     from oracle import hmref
+    cos = hm.Cosmology(dict(p), accuracy="low", engine="analytic")
+    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+    return hmref.CosmoInputs(h=cos.h, omm0=cos.omm0, ombh2=p["ombh2"],
+                             rho_crit_0=float(cos.rho_critical_z(0.0)), rho_crit_zs=cos.rho_critical_z(zs),
+                             Pzk=cos.P_lin_approx(ks, zs), sPzk=cos.P_lin_approx(ksig, zs), ks_sigma2=ksig,
+                             h_of_z_zs=cos.h_of_z(zs))
+
+
+def _cpu_pass(ci, z, ms, ks, p, nxs):
+    """One pass of the oracle over the redshifts z: per-stage seconds and the six spectra."""
+    from hmvec_amd.params import battaglia_defaults
+    from oracle import hmref
+    t = [time.perf_counter()]
+    o = hmref.RefHaloModel(ci, z, ks, ms, p, skip_nfw=True)
+    t.append(time.perf_counter())
+    o.add_nfw_profile("nfw")
+    t.append(time.perf_counter())
+    o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], nxs, 20)
+    t.append(time.perf_counter())
+    o.add_hod("g", mthresh=10 ** 10.5 + z * 0.0)
+    t.append(time.perf_counter())
+    out = [o.get_power(a, b) for a, b in PAIRS]
+    t.append(time.perf_counter())
+    return np.diff(t), out
+
+
+def _cpu_worker(job):
+    """All-core variant: one process per z-slab, each running the single-threaded oracle."""
+    zs, ms, ks, nxs, reps = job
+    from hmvec_amd.params import default_params
+    p = dict(default_params)
+    ci = _cpu_inputs(zs, ks, p)
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        _cpu_pass(ci, zs, ms, ks, p, nxs)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
+    """The CPU oracle (numpy restatement of the reference, pinned by tests/golden) timed on this
+    box's host cores, BEFORE the process touches the GPU: 1 warm-up + best of 3, per stage and
+    total, on a z-subsample of the same workload (numpy elementwise ops, trapz, pocketfft and
+    interp are single-threaded: 1 core effective); plus an all-core variant - the full z grid cut
+    into slabs over a process pool - so that the baseline beside the GPU number is not one core
+    of many.  Returns (record, sample indices, spectra of the sample for the parity check)."""
+    import multiprocessing as mp
+    import platform
+    import scipy
+    from hmvec_amd.params import default_params
+    p = dict(default_params)
     sel = np.linspace(0, zs.size - 1, nz_sample).round().astype(int)
     z = zs[sel]
-    p = dict(default_params)
-    cos = hm.Cosmology(p, accuracy="low", engine="analytic")
-    ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
-    ci = hmref.CosmoInputs(h=cos.h, omm0=cos.omm0, ombh2=p["ombh2"],
-                           rho_crit_0=float(cos.rho_critical_z(0.0)), rho_crit_zs=cos.rho_critical_z(z),
-                           Pzk=cos.P_lin_approx(ks, z), sPzk=cos.P_lin_approx(ksig, z), ks_sigma2=ksig,
-                           h_of_z_zs=cos.h_of_z(z))
-    t0 = time.perf_counter()
-    o = hmref.RefHaloModel(ci, z, ks, ms, p)
-    o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], nxs, 20)
-    o.add_hod("g", mthresh=10 ** 10.5 + z * 0.0)
-    out = [o.get_power(a, b) for a, b in PAIRS]
-    dt = time.perf_counter() - t0
+    ci = _cpu_inputs(z, ks, p)
+    stages = ["mass_function", "nfw", "battaglia_fft", "hod", "six_spectra"]
+    runs = []
+    for _ in range(4):                      # first one is the warm-up
+        st, out = _cpu_pass(ci, z, ms, ks, p, nxs)
+        runs.append(st)
+    runs = np.array(runs[1:])
+    best = runs[np.argmin(runs.sum(axis=1))]
     pts = len(PAIRS) * z.size * ms.size * ks.size
-    return dict(value=pts / dt, unit="grid-points/s", cores=1, kind="port",
-                sample=f"{z.size} of {zs.size} redshifts x {ms.size} x {ks.size}, nxs={nxs}, 6 spectra, "
-                       f"{dt:.1f} s wall, numpy single-thread ({os.cpu_count()} cores available)"), sel, out
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [{k: d.get(k) for k in ("internal_api", "num_threads")} for d in threadpool_info()]
+    except Exception:
+        pools = None
+    avail = len(os.sched_getaffinity(0))
+    rec = dict(value=pts / best.sum(), unit="grid-points/s", cores=1, kind="port",
+               sample=f"{z.size} of {zs.size} redshifts x {ms.size} x {ks.size}, nxs={nxs}, 6 spectra; 1 warm-up + "
+                      f"best of 3 passes ({best.sum():.2f} s best, {runs.sum(axis=1).max():.2f} s worst), numpy single-thread",
+               stages_s=dict(zip(stages, best.tolist())), seconds=float(best.sum()),
+               full_grid_seconds_extrapolated=float(best.sum() * zs.size / z.size),
+               host={"cpu_model": model, "cpu_count": os.cpu_count(), "affinity": avail,
+                     "numpy": np.__version__, "scipy": scipy.__version__, "python": platform.python_version(),
+                     "threadpools": pools})
+    if allcore and avail > 1:
+        nproc = 1
+        for cand in (32, 16, 8, 4, 2):      # a divisor of nz that fits the cores we may use
+            if cand <= avail and zs.size % cand == 0:
+                nproc = cand
+                break
+        per = zs.size // nproc
+        jobs = [(zs[i * per:(i + 1) * per], ms, ks, nxs, 2) for i in range(nproc)]
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(nproc) as pool:      # forked before any GPU initialisation
+            bests = pool.map(_cpu_worker, jobs)
+        wall = time.perf_counter() - t0
+        slowest = max(bests)
+        rec["all_cores"] = dict(value=len(PAIRS) * zs.size * ms.size * ks.size / slowest, unit="grid-points/s",
+                                cores=nproc, seconds=slowest,
+                                sample=f"all {zs.size} redshifts as {nproc} z-slabs of {per} over a process pool "
+                                       f"(one single-threaded oracle per core; slowest slab's best of 2; pool wall {wall:.1f} s)")
+    return rec, sel, out
+
+
+# ------------------------------------------------------------------------------------------------
+# byte and instruction models of the three large kernels
+# ------------------------------------------------------------------------------------------------
+def load_profile(name):
+    path = os.path.join(PROFILE_DIR, name)
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
+
+
+def power_bytes_moved(nzl, nm, nk, npair, nconst, vec):
+    """HBM bytes one hmg_power_batch launch moves, from the launch's own skip rule: the NFW tensor is
+    read whole; of the Battaglia tensor every (row, k-tile) whose tile lies inside the row's constant
+    prefix (nconst[row] >= tile end) is not read.  Plus the coefficient rows, hints, P_lin and the
+    2*npair output rows."""
+    tile = 64 * vec
+    ends = np.minimum(nk, (np.arange((nk + tile - 1) // tile) + 1) * tile)
+    widths = np.diff(np.concatenate([[0], ends]))
+    read = (nconst.reshape(-1, 1) < ends[None, :]) * widths[None, :]
+    tens = 8.0 * nzl * nm * nk + 8.0 * float(read.sum())
+    stride = 2 + 3 * 3 * 3                        # coefficient doubles per (z,m): hmgrid.hip power_batch_prep
+    side = 8.0 * nzl * nm * (stride + 2)          # coefficient rows + hint count/value
+    outs = 8.0 * nzl * nk * (2 * npair + 1)       # spectra + P_lin
+    return tens + side + outs, tens
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)     # 0.8 ms each: clocks and caches settle after ~10
+    ap.add_argument("--steps", type=int, default=100)     # 0.6 ms each: clocks and caches settle after ~10
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nz", type=int, default=32)
     ap.add_argument("--nm", type=int, default=512)
     ap.add_argument("--nk", type=int, default=4096)
     ap.add_argument("--nxs", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the launches of every step one by one")
+    ap.add_argument("--lanes", action="store_true",
+                    help="independent stages on separate HIP streams (concurrent graph branches)")
     ap.add_argument("--per-pair", action="store_true", help="six hmg_power launches instead of one hmg_power_batch")
-    ap.add_argument("--limber", action="store_true",
-                    help="Config 5: after the timed region also time C_kk and C_kg at 2000 multipoles "
-                         "(lzs=2.5, gzs=0.8) on the gathered spectra, rank 0; reported as extra fields")
-    ap.add_argument("--detail", action="store_true",
-                    help="also record per-stage and NFW/FFT-kernel HIP events in the timed region (each event "
-                         "costs a few us of stream time; off by default so they do not perturb `value`)")
-    ap.add_argument("--cpu-sample-nz", type=int, default=16)
+    ap.add_argument("--no-limber", action="store_true",
+                    help="skip the Config-5 leg (C_kk and C_kg at 2000 multipoles on the gathered spectra)")
+    ap.add_argument("--stages", action="store_true",
+                    help="also record per-stage HIP events (eager launches only; a few us of stream time each)")
+    ap.add_argument("--cpu-sample-nz", type=int, default=8)
+    ap.add_argument("--dry-run", action="store_true", help="launcher only: print the rank commands and exit")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run):
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    # Multi-process GPU work on this platform needs dmabuf IPC (the task environment exports it; keep it
+    # if a launcher dropped it).  Set here, in the benchmark, before anything loads the HIP runtime -
+    # the library itself leaves the process environment alone.
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    zs, ms, ks = workload(args.nz, args.nm, args.nk)
+    K, W = args.steps, args.warmup
+
+    # ---- CPU baseline first: nothing in this process has touched the GPU yet
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(zs, ms, ks, min(args.cpu_sample_nz, zs.size), args.nxs)
+
+    if args.lanes:
+        os.environ["HMG_LANES"] = "1"
     import hmvec_amd as hm
     from hmvec_amd import _native as nat
     from hmvec_amd.dist import RcclComm, ShardedSpectra, slab_bounds
 
-    zs, ms, ks = workload(args.nz, args.nm, args.nk)
     lo, hi = slab_bounds(zs.size, world, rank)
     zloc = zs[lo:hi]
-    K, W = args.steps, args.warmup
-    if 16 + 16 * K > nat.EVENT_SLOTS:
-        sys.exit("too many steps for the event-slot table")
-
     ctx = nat.Context(local_rank)
-    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'solo')}"
+    tag = os.environ.get("HMG_LAUNCH_TAG") or \
+        f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'solo')}"
     comm = RcclComm(ctx, rank, world, tag)
+    rccl_rank, rccl_ranks = comm.info()
 
     mthr = 10 ** 10.5 + zloc * 0.0
     h = hm.HaloModel(zloc, ks, ms=ms, accuracy="low", engine="analytic", ctx=ctx)
     h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=args.nxs)
     h.add_hod("g", mthresh=mthr)
     spec = ShardedSpectra(h, comm, zs.size, PAIRS)
+    npair = len(PAIRS)
 
     BR = {"power": nat.KERNEL_POWER, "nfw": nat.KERNEL_NFW, "fft": nat.KERNEL_PROFILE_FFT}
-    SLOTS_PER_STEP = 16
+    EV_BR = {"power": (40, 41), "nfw": (42, 43), "fft": (44, 45)}      # bracket slots (HaloModel: 0-3, gather: 8-9)
+    EV_STAGE = 48                                                       # 48..53 stage marks (--stages)
 
-    def step(base=None):
-        """One full pass of the hot path.  base = first event slot of this step (timed region
-        only): [0..5] stage marks, [6,7] mass-integral kernel, [8,9] NFW kernel, [10,11] FFT chain."""
+    def compute(brackets=False, stages=False):
+        """The launches of one pass (everything but the gather): capturable."""
         def mark(i):
-            if base is not None and args.detail:
-                ctx.record(base + i)
-        def bracket(name, i):
-            if base is not None and args.detail:
-                ctx.call("hmg_bracket_next", BR[name], base + i, base + i + 1)
+            if stages:
+                ctx.record(EV_STAGE + i)
+        def bracket(name):
+            if brackets and not (name == "power" and args.per_pair):
+                ctx.call("hmg_bracket_next", BR[name], EV_BR[name][0], EV_BR[name][1])
         mark(0)
         h.init_mass_function(ms)
         mark(1)
-        bracket("nfw", 8)
+        bracket("nfw")
         h.add_nfw_profile("nfw", ignore_existing=True)
         mark(2)
-        bracket("fft", 10)
+        bracket("fft")
         h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=args.nxs, ignore_existing=True)
         mark(3)
         h.add_hod("g", mthresh=mthr, ignore_existing=True)
         mark(4)
-        spec.run((base + 6, base + 7) if base is not None and (args.detail or not args.per_pair) else None,
-                 batched=not args.per_pair)
+        bracket("power")
+        spec.launch_spectra(batched=not args.per_pair)
         mark(5)
 
-    # Clock / cache preconditioning before the W warm-up steps: a 0.8 ms step leaves the GPU in its
-    # idle power state for the first few milliseconds (5 timed steps measure 0.92 ms, 100 measure 0.75),
-    # so the steady state the metric is about needs ~50 ms of work first.  Untimed, disclosed in the JSON.
+    # ---- one eager pass sizes every scratch arena; then the step is captured (plain and bracketed)
+    for _ in range(2):
+        spec.wait_gathered(); compute(); spec.gather()
+    ctx.sync()
+    use_graph = not args.no_graph and not args.stages
+    g_plain = g_brack = None
+    events_in_graph = False
+    if use_graph:
+        g_plain = ctx.capture(lambda: compute())
+        g_brack = ctx.capture(lambda: compute(brackets=True))
+        ctx.replay(g_brack)
+        ctx.sync()
+        try:    # do events recorded by graph nodes carry timestamps on this runtime?
+            t = ctx.elapsed_ms(*EV_BR["nfw"])
+            events_in_graph = 0.0 < t < 100.0
+        except nat.NativeError:
+            events_in_graph = False
+
+    kern_ms = {k: [] for k in BR}
+    stage_ms = []
+
+    def read_brackets():
+        for k in BR:
+            if not (k == "power" and args.per_pair):
+                kern_ms[k].append(ctx.elapsed_ms(*EV_BR[k]))
+        if args.stages:
+            stage_ms.append([ctx.elapsed_ms(EV_STAGE + j, EV_STAGE + j + 1) for j in range(5)])
+
+    def step(timed_index=None):
+        """One full pass.  Every BRACKET_EVERY-th timed step carries the kernel brackets; their event
+        times are read just before the next bracketed step overwrites them (the GPU still has the
+        steps in between queued, so the host-side wait opens no bubble)."""
+        bracketed = timed_index is not None and timed_index % BRACKET_EVERY == 0
+        if bracketed and timed_index > 0:
+            read_brackets()
+        spec.wait_gathered()
+        if use_graph and (not bracketed or events_in_graph):
+            ctx.replay(g_brack if bracketed else g_plain)
+        else:
+            compute(brackets=bracketed, stages=bracketed and args.stages)
+        spec.gather()
+
+    # Clock / cache preconditioning before the W warm-up steps: a sub-millisecond step leaves the GPU in
+    # its idle power state for the first few milliseconds, so the steady state the metric is about needs
+    # ~50 ms of work first.  Untimed, disclosed in the JSON.
     PRECONDITION = 64
-    for _ in range(PRECONDITION):
-        step()
-    for _ in range(W):
+    for _ in range(PRECONDITION + W):
         step()
     comm.barrier()
     ctx.sync()
-    npair = len(PAIRS)
     t0 = time.perf_counter()
     for s in range(K):
-        step(16 + s * SLOTS_PER_STEP)
+        step(s)
     t_issue = time.perf_counter() - t0        # host time to enqueue K steps (launches are asynchronous)
     comm.barrier()
     ctx.sync()
     dt = time.perf_counter() - t0
+    read_brackets()
     dt_all = comm.allgather_host([dt]).reshape(-1) if world > 1 else np.array([dt])
     dt_max = float(dt_all.max())
+    kms = {k: (float(np.mean(v)) if v else None) for k, v in kern_ms.items()}
 
-    # HIP-event timings recorded inside the timed region, on the stream the kernels run on
-    nzl = zloc.size
-    stage_ms = np.zeros(5)
-    kern_ms = {"power": 0.0, "nfw": 0.0, "fft": 0.0}
-    for s in range(K):
-        base = 16 + s * SLOTS_PER_STEP
-        if not args.per_pair:
-            kern_ms["power"] += ctx.elapsed_ms(base + 6, base + 7)
-        if args.detail:
-            for j in range(5):
-                stage_ms[j] += ctx.elapsed_ms(base + j, base + j + 1)
-            kern_ms["nfw"] += ctx.elapsed_ms(base + 8, base + 9)
-            kern_ms["fft"] += ctx.elapsed_ms(base + 10, base + 11)
-    stage_ms /= K
-    kern_ms = {k: v / K for k, v in kern_ms.items()}
-    B, nm_, nk_, nxs = nzl * ms.size, ms.size, ks.size, args.nxs
+    nzl, nm_, nk_, nxs = zloc.size, ms.size, ks.size, args.nxs
+    B = nzl * nm_
     tens_bytes = 8.0 * B * nk_
-    # algorithmic HBM bytes per launch (DESIGN.md "Roofline accounting", SURVEY 8d)
-    alg = {
-        # two distinct tensors (nfw, electron) read once + 12 (nz,nk) outputs + Pzk + per-(z,m) scalars
-        "power": 2 * tens_bytes + 8.0 * nzl * nk_ * (2 * npair + 1) + 8.0 * B * 8,
-        "nfw": tens_bytes,                                     # one 8 B store per grid point
-        "fft": 2 * 8.0 * B * nxs + 2 * 16.0 * B * (nxs // 2 + 1) + tens_bytes,
-    }
-    if args.per_pair:
-        if not args.detail:
-            sys.exit("--per-pair needs --detail (the six launches are timed through the stage events)")
-        kern_ms["power"] = stage_ms[4]
-        alg["power"] = float(sum(power_alg_bytes(nzl, nm_, nk_, d) for d in PAIR_TENSORS))
-    gbs = {k: (alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else None) for k in alg}
 
-    # host <-> device transfer cost if the boundary handed over host buffers (never part of `value`)
+    if rank != 0:
+        comm.barrier()
+        comm.close()
+        ctx.close()
+        return
+
+    # ---- bytes: the implementation's own model (DESIGN.md section 4) and, for the default configuration,
+    # the PMC counters of profiles/r02 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+    default_cfg = (args.nz, args.nm, args.nk, args.nxs) == (32, 512, 4096, 5000) and world == 1 and not args.per_pair
+    pmc = load_profile("pmc_traffic.json") if default_cfg else None
+    sq = load_profile("sq_issue_counters.json") if default_cfg else None
+
+    def pmc_bytes(sub):
+        if not pmc:
+            return None
+        for name, rec in pmc["kernels"].items():
+            if sub in name:
+                return rec["hbm_bytes_per_launch_corrected"]
+        return None
+
+    def valu(sub):
+        if not sq:
+            return None
+        for name, rec in sq["kernels"].items():
+            if sub in name and rec.get("SQ_WAVES"):
+                per_wave = rec["SQ_INSTS_VALU"] / rec["SQ_WAVES"]
+                return {"valu_insts_per_wave": per_wave,
+                        "valu_issue_bound_ms": rec["SQ_INSTS_VALU"] * FP64_VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3}
+        return None
+
+    hint_n = h.uk_profiles.hint("electron")[0]
+    vec = 2 if nk_ % 2 == 0 and (nk_ + 127) // 128 * nzl >= 256 else 1
+    if hint_n is not None and not args.per_pair:
+        nconst = hint_n.numpy().view(np.int32)[:B]
+        pw_model, pw_tens = power_bytes_moved(nzl, nm_, nk_, npair, nconst, vec)
+    else:
+        pw_model, pw_tens = 2 * tens_bytes + 8.0 * nzl * nk_ * (2 * npair + 1) + 8.0 * B * 31, 2 * tens_bytes
+    alg = {"power": 2 * tens_bytes + 8.0 * nzl * nk_ * (2 * npair + 1) + 8.0 * B * 8,     # SURVEY 8d W_mass, batched
+           "nfw": tens_bytes,
+           "fft": 2 * 8.0 * B * nxs + 2 * 16.0 * B * (nxs // 2 + 1) + tens_bytes}     # SURVEY 8d W_fft (unfused chain)
+    model = {"power": pw_model, "nfw": tens_bytes + 8.0 * B * 40, "fft": tens_bytes + 8.0 * B * 10}
+
+    def kernel_entry(key, sub, bound, note):
+        ms_ = kms[key]
+        moved = pmc_bytes(sub) or model[key]
+        e = {"bound": bound, "ms": ms_, "bytes_moved": moved,
+             "bytes_source": "pmc (profiles/r02/pmc_traffic.json)" if pmc_bytes(sub) else "model (DESIGN.md section 4)",
+             "bytes_model": model[key], "hbm_GBps": moved / (ms_ * 1e-3) / 1e9 if ms_ else None,
+             "hbm_frac": moved / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ else None,
+             "survey_alg_bytes": alg[key], "note": note}
+        v = valu(sub)
+        if v:
+            e.update(v)
+            e["valu_issue_frac"] = v["valu_issue_bound_ms"] / ms_ if ms_ else None
+        return e
+
+    kernels = {
+        "power_batch_kernel": kernel_entry("power", "power_batch_kernel", "hbm",
+                                           "fused 1h+2h mass integrals of all 6 spectra, 1 launch/step; the constant "
+                                           "left-fill prefix of the Battaglia tensor is substituted, not read"),
+        "nfw_kernel": kernel_entry("nfw", "nfw_kernel", "fp64-valu",
+                                   "series / Si-Ci evaluation per point, one 8-B store per point"),
+        "profile_fused_kernel": kernel_entry("fft", "profile_fused_kernel", "fp64-valu + LDS",
+                                             "integrand + in-LDS packed-real FFT + k-interpolation per (z,m) row; "
+                                             "HBM traffic = the output row"),
+    }
+    pw = kernels["power_batch_kernel"]
+    step_bytes = None
+    if pmc:
+        step_bytes = float(sum(r["hbm_bytes_per_launch_corrected"] * r.get("launches_per_step", 1)
+                               for r in pmc["kernels"].values()))
+    if step_bytes is None:
+        step_bytes = float(sum(model.values()))
+
+    # ---- result hand-over over PCIe (never part of `value`): one device block -> one pinned host block
     pcie = None
-    if rank == 0 and world == 1:
-        res_host = [np.empty(a.shape) for a in spec.full]        # caller-provided host buffers
-        for r in res_host:
-            r[...] = 0.0                                           # touch the pages once
+    if world == 1:
+        blk = h.spectra_block(PAIRS)
+        blk.compute(); blk.fetch()                                  # allocations, first touch
         t1 = time.perf_counter()
         for _ in range(5):
-            for a, r in zip(spec.full, res_host):
-                nat.check(ctx.lib.hmg_memcpy_d2h(ctx.handle, r.ctypes.data, a.ptr, r.nbytes))
+            blk.fetch()
         d2h_ms = (time.perf_counter() - t1) / 5 * 1e3
         ins = [h.Pzk, h.sPzk, zs, ms, ks]
         t1 = time.perf_counter()
@@ -221,93 +470,92 @@ def main():
             keep = [ctx.upload(a) for a in ins]
         ctx.sync()
         h2d_ms = (time.perf_counter() - t1) / 5 * 1e3
-        pcie = {"d2h_results_ms": d2h_ms, "h2d_inputs_ms": h2d_ms,
-                "results_MB": sum(a.nbytes for a in res_host) / 1e6, "inputs_MB": sum(a.nbytes for a in ins) / 1e6,
+        pcie = {"d2h_results_ms": d2h_ms, "h2d_inputs_ms": h2d_ms, "results_MB": blk.nbytes / 1e6,
+                "inputs_MB": sum(a.nbytes for a in ins) / 1e6,
+                "d2h_GBps": blk.nbytes / d2h_ms / 1e6,
                 "ms_per_step_incl_transfers": dt_max / K * 1e3 + d2h_ms + h2d_ms,
-                "note": "pageable (pre-touched) numpy buffers, one synchronous copy per array"}
+                "note": "results: 12 (nz,nk) spectra in one device block, one asynchronous copy into one pinned host "
+                        "block, numpy views handed out (HaloModel.spectra_block); inputs: pageable numpy uploads"}
         del keep
 
+    # ---- Config 5: Limber C_kk + C_kg at 2000 multipoles on the gathered, device-resident spectra
     limber = None
-    if args.limber and rank == 0:
+    if not args.no_limber:
         full = hm.Cosmology(dict(h.p), accuracy="low", engine="analytic")
         full.ctx = ctx
         ells = np.linspace(100, 6000, 2000)
         iP = {p: i for i, p in enumerate(PAIRS)}
-        def total(pair):
+        def dev_pair(pair):
             i = iP[pair]
-            return spec.full[2 * i].numpy() + spec.full[2 * i + 1].numpy()
-        Pmm, Pgm = total(("nfw", "nfw")), total(("g", "nfw"))
-        full.C_kk(ells, zs, ks, Pmm, lzs1=2.5, lzs2=2.5)          # warm-up (uploads, first launch)
+            return (spec.full[2 * i], spec.full[2 * i + 1])       # (P_1h, P_2h), summed inside the kernel
+        run = lambda: (full.C_kk(ells, zs, ks, dev_pair(("nfw", "nfw")), lzs1=2.5, lzs2=2.5),       # noqa: E731
+                       full.C_kg(ells, zs, ks, dev_pair(("g", "nfw")), gzs=0.8, lzs=2.5))
+        run()                                                      # uploads of windows, first launch
         ctx.sync()
+        reps = 5
         t1 = time.perf_counter()
-        ckk = full.C_kk(ells, zs, ks, Pmm, lzs1=2.5, lzs2=2.5)
-        ckg = full.C_kg(ells, zs, ks, Pgm, gzs=0.8, lzs=2.5)
-        limber = {"ells": 2000, "C_kk+C_kg_ms": (time.perf_counter() - t1) * 1e3,
+        for _ in range(reps):
+            ckk, ckg = run()
+        lim_ms = (time.perf_counter() - t1) / reps * 1e3
+        limber = {"ells": 2000, "C_kk+C_kg_ms": lim_ms,
+                  "config5_ms_end_to_end": dt_max / K * 1e3 + lim_ms,
                   "C_kk[0]": float(ckk[0]), "C_kg[0]": float(ckg[0]),
-                  "note": "host wall incl. window functions, H2D of P(z,k) and D2H of C_ell"}
+                  "note": "host wall per (C_kk, C_kg) pair incl. the window functions on the host, their upload and "
+                          "the D2H of C_ell; P(z,k) stays in HBM.  config5 = one step + this"}
 
-    # HBM traffic of the roofline kernel from the committed PMC profile (same config only)
-    traffic = None
-    default_cfg = (args.nz, args.nm, args.nk, args.nxs) == (32, 512, 4096, 5000) and world == 1 and not args.per_pair
-    pmc_path = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
-    if default_cfg and os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)["kernels"]
-        for name, rec in pmc.items():
-            if "power_batch_kernel" in name:
-                traffic = rec["hbm_bytes_per_launch_corrected"]
-
-    if rank == 0:
-        pts = npair * zs.size * ms.size * ks.size
-        out = {
-            "metric": "(z,m,k) grid-points/sec for P_1h+P_2h",
-            "value": pts * K / dt_max, "unit": "grid-points/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
-            "host_issue_ms_per_step": t_issue / K * 1e3, "preconditioning_steps": PRECONDITION,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Config 3: zs={zs.size} ms={ms.size} ks={ks.size}, analytic NFW + "
-                                   f"Battaglia AGN electron (nxs={args.nxs}, xmax=20) + HOD(mthresh=10^10.5), "
-                                   f"6 auto/cross spectra 1h+2h, full path per step",
-                       "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
-                       "grid_points_per_step": pts},
-            "roofline": {"kernel": "hmg::power_batch_kernel (fused 1h+2h mass integrals of all 6 spectra, 1 launch/step)"
-                                   if not args.per_pair else "hmg::power_kernel x6 (per-pair path)",
-                         "bound": "hbm", "achieved": gbs["power"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs["power"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "(2*FETCH+WRITE)*1024 bytes per launch)" if traffic else None,
-                         "alg_bytes_per_launch": alg["power"], "ms_per_launch": kern_ms["power"],
-                         "hbm_actual_GBps": (traffic / (kern_ms["power"] * 1e-3) / 1e9) if traffic else None,
-                         "note": "traffic < algorithmic bytes: 62 % of the Battaglia tensor is np.interp's constant "
-                                 "left fill, reported by hmg_profile_fft as a per-row hint and substituted instead of "
-                                 "read (bit-identical results; HMG_NO_HINTS=1 disables)"},
-        }
-        if pcie is not None:
-            out["pcie"] = pcie
-        if limber is not None:
-            out["limber"] = limber
-        if args.detail:
-            out["kernels"] = {
-                "nfw_kernel": {"bound": "fp64-valu", "ms": kern_ms["nfw"], "alg_GBps": gbs["nfw"],
-                               "note": "2 Si/Ci rational evaluations + 2 sincos per 8 B written"},
-                "profile_fused_kernel": {"bound": "fp64-valu + LDS", "ms": kern_ms["fft"],
-                                         "alg_GBps": 8.0 * B * nk_ / (kern_ms["fft"] * 1e-3) / 1e9,
-                                         "note": "integrand + in-LDS packed-real FFT + k-interpolation; HBM traffic = output row only"},
-            }
-            out["stages_ms"] = dict(zip(["mass_function", "nfw", "battaglia_fft", "hod", "spectra+gather"],
-                                        stage_ms.tolist()))
-        if world == 1 and not args.no_cpu_baseline:
-            cb, sel, ref = cpu_baseline(zs, ms, ks, args.cpu_sample_nz, args.nxs)
-            res = spec.results()
-            worst = 0.0
-            for (a, b), R in zip(PAIRS, ref):
-                P = (res[(a, b)][0] + res[(a, b)][1])[sel]
-                tol = 1e-8 * np.abs(R) + 1e-12 * np.max(np.abs(R), axis=-1, keepdims=True)
-                worst = max(worst, float(np.max(np.abs(P - R) / tol)))
-            cb["parity_worst_dP_over_tol"] = worst
-            out["cpu_baseline"] = cb
-        print(json.dumps(out))
+    pts = npair * zs.size * ms.size * ks.size
+    out = {
+        "metric": "(z,m,k) grid-points/sec for P_1h+P_2h",
+        "value": pts * K / dt_max, "unit": "grid-points/s",
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
+        "host_issue_ms_per_step": t_issue / K * 1e3, "preconditioning_steps": PRECONDITION,
+        "launch_mode": ("hip-graph replay" if use_graph else "eager launches") + (", lanes" if args.lanes else ""),
+        "kernel_events": f"HIP events around the three large kernels on every {BRACKET_EVERY}th timed step"
+                         + (" (graph event nodes)" if use_graph and events_in_graph else " (eager launches)"),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Config 3: zs={zs.size} ms={ms.size} ks={ks.size}, analytic NFW + "
+                               f"Battaglia AGN electron (nxs={args.nxs}, xmax=20) + HOD(mthresh=10^10.5), "
+                               f"6 auto/cross spectra 1h+2h, full path per step",
+                   "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+                   "grid_points_per_step": pts},
+        "roofline": {"kernel": "hmg::power_batch_kernel" if not args.per_pair else "hmg::power_kernel x6 (per-pair path)",
+                     "bound": "hbm", "achieved": pw["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": pw["hbm_frac"], "traffic": pmc_bytes("power_batch_kernel"),
+                     "traffic_source": ("stored profile profiles/r02/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                        "separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch "
+                                        "(gfx950 FETCH_SIZE correction)") if pmc else None,
+                     "bytes_moved": pw["bytes_moved"], "bytes_source": pw["bytes_source"], "bytes_model": pw["bytes_model"],
+                     "ms_per_launch": kms["power"],
+                     "alg_bytes_per_launch": alg["power"],
+                     "alg_equiv_GBps": alg["power"] / (kms["power"] * 1e-3) / 1e9 if kms["power"] else None,
+                     "note": "achieved/frac use the bytes the launch actually moves (counter bytes when a profile of this "
+                             "configuration is stored, else the launch's own skip rule evaluated on the hint array); "
+                             "alg_equiv_GBps prices the SURVEY 8d algorithmic bytes, of which the hinted constant prefix "
+                             "is never read"},
+        "kernels": kernels,
+        "step_hbm_bytes": step_bytes,
+        "step_hbm_frac": step_bytes / (dt_max / K) / 1e9 / HBM_PEAK_GBS,
+        "survey_alg_bytes_per_step": float(sum(alg.values()) + (sum([1, 1, 1, 2, 1, 2]) - 2) * tens_bytes),
+    }
+    if args.stages and stage_ms:
+        out["stages_ms"] = dict(zip(["mass_function", "nfw", "battaglia_fft", "hod", "spectra"],
+                                    np.mean(np.array(stage_ms), axis=0).tolist()))
+    if pcie is not None:
+        out["pcie"] = pcie
+    if limber is not None:
+        out["limber"] = limber
+    if cpu is not None:
+        cb, sel, ref = cpu
+        res = spec.results()
+        worst = 0.0
+        for (a, b), R in zip(PAIRS, ref):
+            P = (res[(a, b)][0] + res[(a, b)][1])[sel]
+            tol = 1e-8 * np.abs(R) + 1e-12 * np.max(np.abs(R), axis=-1, keepdims=True)
+            worst = max(worst, float(np.max(np.abs(P - R) / tol)))
+        cb["parity_worst_dP_over_tol"] = worst
+        out["cpu_baseline"] = cb
+    print(json.dumps(out))
     comm.barrier()
     comm.close()
     ctx.close()

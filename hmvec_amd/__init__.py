@@ -8,6 +8,7 @@ first kernel call does (and fails loudly if it is not built).
 """
 from .params import battaglia_defaults, default_params  # noqa: F401
 from .cosmology import Cosmology  # noqa: F401
+from .background import AnalyticBackground, CambBackground, TabulatedBackground  # noqa: F401
 from .halomodel import HaloModel  # noqa: F401
 from .functions import *  # noqa: F401,F403  (the reference's free functions, GPU-backed)
 from .fft import generic_profile_fft  # noqa: F401  (hmvec/hmvec.py:3 star-imports it into the package)

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -60,6 +60,14 @@ SIGNATURES = {
     "hmg_memcpy_d2h": [_P, _P, _P, _Z],
     "hmg_memcpy_d2d": [_P, _P, _P, _Z],
     "hmg_sync": [_P],
+    "hmg_host_alloc": [_P, _Z, C.POINTER(_P)],
+    "hmg_host_free": [_P, _P],
+    "hmg_memcpy_d2h_async": [_P, _P, _P, _Z],
+    "hmg_graph_begin": [_P],
+    "hmg_graph_end": [_P, C.POINTER(_I)],
+    "hmg_graph_abort": [_P],
+    "hmg_graph_launch": [_P, _I],
+    "hmg_graph_destroy": [_P, _I],
     "hmg_lane_set": [_P, _I],
     "hmg_event_wait": [_P, _I],
     "hmg_event_record": [_P, _I],
@@ -81,7 +89,9 @@ SIGNATURES = {
                   _D, _D, _P, _P],
     "hmg_power_batch": [_P, _I, _I, _I, _I, C.POINTER(Tracer), _I, C.POINTER(_I), C.POINTER(_I),
                         _P, _P, _P, _P, _P, _P, _D, _D, C.POINTER(_P), C.POINTER(_P)],
-    "hmg_limber": [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "hmg_power_2halo_terms": [_P, _I, _I, _I, C.POINTER(Tracer), C.POINTER(Tracer), _P, _P, _P, _P, _P, _D,
+                              _P, _P, _P],
+    "hmg_limber": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "hmg_fn2d": [_P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_D), _I, _P],
     "hmg_mstellar_halo": [_P, _I, _I, _P, _P, _P],
     "hmg_trapz_rows": [_P, _I, _I, _P, _P, _P],
@@ -91,6 +101,8 @@ SIGNATURES = {
     "hmg_comm_init": [_P, C.c_char * COMM_ID_BYTES, _I, _I],
     "hmg_comm_allgather": [_P, _P, _P, _Z],
     "hmg_comm_allgather_multi": [_P, _I, C.POINTER(_P), C.POINTER(_P), _Z],
+    "hmg_comm_gather_async": [_P, _I, C.POINTER(_P), C.POINTER(_P), _Z, _I, _I, _I],
+    "hmg_comm_info": [_P, C.POINTER(_I), C.POINTER(_I)],
     "hmg_comm_barrier": [_P],
     "hmg_comm_destroy": [_P],
 }
@@ -107,10 +119,6 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU "
             "fallback. Run `make -C hmvec_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
-    # The host driver of this platform only supports dmabuf IPC; RCCL's peer-to-peer set-up fails with
-    # hipIpcGetMemHandle "invalid argument" otherwise.  Must be in the environment before the HSA
-    # runtime initialises, i.e. before the library (and with it libamdhip64) is loaded.
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
@@ -160,6 +168,7 @@ class DeviceArray:
         return v
 
     def free(self):
+        """Hand the block back to the context's free list (no device synchronisation)."""
         if self._owner is True and self.ptr and self.ctx is not None and self.ctx.handle:
             self.ctx.lib.hmg_free(self.ctx.handle, self.ptr)
         self.ptr = 0
@@ -167,6 +176,31 @@ class DeviceArray:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """Page-locked host block viewed as a numpy array: the destination of asynchronous D2H copies
+    (hmg_memcpy_d2h_async).  Owns the block; numpy views into it keep this object alive through
+    ``.base``."""
+
+    def __init__(self, ctx, shape):
+        self.ctx = ctx
+        shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        n = int(np.prod(shape)) if shape else 1
+        p = C.c_void_p()
+        check(ctx.lib.hmg_host_alloc(ctx.handle, n * 8, C.byref(p)))
+        self.ptr = p.value
+        buf = (C.c_double * n).from_address(self.ptr)
+        buf._hmg_owner = self                     # the ctypes buffer is numpy's base object
+        self.array = np.frombuffer(buf, dtype=np.float64).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.ctx.lib.hmg_host_free(self.ctx.handle, self.ptr)
+            self.ptr = 0
         except Exception:
             pass
 
@@ -232,6 +266,27 @@ class Context:
 
     def call(self, name, *args):
         check(getattr(self.lib, name)(self.handle, *args))
+
+    # captured steps
+    def capture(self, fn):
+        """Run ``fn()`` (launch-only: no allocation, upload, download or synchronisation) inside a
+        HIP-graph capture and return the graph id for ``replay``."""
+        check(self.lib.hmg_graph_begin(self.handle))
+        try:
+            fn()
+        except BaseException:
+            self.lib.hmg_graph_abort(self.handle)
+            raise
+        gid = C.c_int()
+        check(self.lib.hmg_graph_end(self.handle, C.byref(gid)))
+        return gid.value
+
+    def replay(self, gid):
+        check(self.lib.hmg_graph_launch(self.handle, gid))
+
+    def copy_to_pinned(self, pinned, src):
+        """Asynchronous D2H of DeviceArray ``src`` into PinnedArray ``pinned`` on the current lane."""
+        check(self.lib.hmg_memcpy_d2h_async(self.handle, pinned.ptr, src.ptr, src.nbytes))
 
 
 _default_ctx = {}

@@ -114,3 +114,65 @@ class CambBackground:
 
     def __getattr__(self, name):
         return getattr(self.results, name)
+
+
+class TabulatedPowerInterpolator:
+    """``.P(zs, ks, grid=True)`` over a table P[z, k], the one call the path makes on CAMB's
+    ``get_matter_power_interpolator`` result (hmvec/cosmology.py:229,369,381).  Like CAMB's
+    interpolator this is a bivariate spline of ln P in (z, ln k) - cubic where the table has at
+    least four nodes along an axis, lower order otherwise."""
+
+    def __init__(self, zs, ks, P):
+        from scipy.interpolate import RectBivariateSpline
+        self.zs = np.asarray(zs, dtype=np.float64)
+        self.ks = np.asarray(ks, dtype=np.float64)
+        P = np.asarray(P, dtype=np.float64)
+        if P.shape != (self.zs.size, self.ks.size) or np.any(P <= 0):
+            raise ValueError("P must be a positive (nz, nk) table")
+        kz, kk = min(3, self.zs.size - 1), min(3, self.ks.size - 1)
+        if kz < 1 or kk < 1:
+            raise ValueError("the table needs at least two redshifts and two wavenumbers")
+        self._spl = RectBivariateSpline(self.zs, np.log(self.ks), np.log(P), kx=kz, ky=kk, s=0)
+
+    def P(self, z, k, grid=True):
+        z = np.atleast_1d(np.asarray(z, dtype=np.float64))
+        k = np.atleast_1d(np.asarray(k, dtype=np.float64))
+        if z.min() < self.zs[0] or z.max() > self.zs[-1] or k.min() < self.ks[0] or k.max() > self.ks[-1]:
+            raise ValueError("requested (z, k) outside the tabulated P(k, z)")
+        if grid:
+            zi, ki = np.argsort(z), np.argsort(k)          # the spline wants ascending axes
+            out = np.empty((z.size, k.size))
+            out[np.ix_(zi, ki)] = np.exp(self._spl(z[zi], np.log(k[ki]), grid=True))
+            return out
+        return np.exp(self._spl(z, np.log(k), grid=False))
+
+
+class TabulatedBackground(AnalyticBackground):
+    """Background + a tabulated linear (and optionally non-linear) matter power spectrum: the
+    provider to use when the Boltzmann code ran elsewhere (CAMB is not installable on the GPU
+    boxes) and its ``P(k, z)`` table travels as data.  ``accuracy='medium'`` then normalises the
+    Eisenstein-Hu shape to the table at ``knorm`` and ``accuracy='high'`` integrates the table
+    itself, exactly the two code paths of hmvec/cosmology.py:255-260,353-382.  Distances and
+    H(z) come from the closed-form background unless ``base`` supplies another provider."""
+
+    def __init__(self, params, zs, ks, P_lin, P_nonlin=None, base=None):
+        AnalyticBackground.__init__(self, params["H0"], params["ombh2"], params["omch2"], params.get("omk", 0.0),
+                                    params.get("w0", -1.0), params.get("wa", 0.0), params.get("YHe"))
+        self._base = base
+        self._lin = TabulatedPowerInterpolator(zs, ks, P_lin)
+        self._nonlin = None if P_nonlin is None else TabulatedPowerInterpolator(zs, ks, P_nonlin)
+
+    def pk_interpolator(self, zs, kmax, var="total", nonlinear=False):
+        if nonlinear:
+            if self._nonlin is None:
+                raise NotImplementedError("no non-linear table was given to this provider")
+            return self._nonlin
+        return self._lin
+
+    def __getattribute__(self, name):
+        if name in ("hubble_parameter", "h_of_z", "comoving_radial_distance", "angular_diameter_distance",
+                    "angular_diameter_distance2", "get_Omega"):
+            base = object.__getattribute__(self, "_base")
+            if base is not None:
+                return getattr(base, name)
+        return object.__getattribute__(self, name)

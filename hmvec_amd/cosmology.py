@@ -387,23 +387,16 @@ class Cosmology(object):
 
     def limber_integral(self, ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis):
         """C(ell) = int dz (H/c) W1 W2 P(z, k=(ell+1/2)/chi) / chi^2 on the GPU (hmg_limber);
-        argument meaning as hmvec/cosmology.py:867-904.  Pzks may be a numpy (nz,nk) array or
-        a DeviceArray already resident in HBM."""
+        argument meaning as hmvec/cosmology.py:867-904.  Pzks may be a numpy (nz,nk) array, a
+        DeviceArray already resident in HBM, or a (P_1h, P_2h) pair of DeviceArrays (their sum is
+        taken inside the kernel)."""
         return _limber(self._ctx(), ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis)
 
     def C_gy(self, ells, zs, ks, Pgp, gzs, gdndz=None, zmin=None, zmax=None):
-        """Galaxy x Compton-y projection.  The reference's body (hmvec/cosmology.py:570-583) reads
-        two undefined names (``dndz``, ``Ppy``) and raises NameError on every call; this is the
-        computation its signature and its siblings C_gg / C_ky imply: galaxy window x unit window."""
-        gzs = np.asarray(gzs, dtype=np.float64)
-        chis = self.comoving_radial_distance(gzs)
-        hzs = self.h_of_z(gzs)
-        if gzs.size > 1:
-            Wz2s = gdndz / _trapz(gdndz, gzs)
-        else:
-            dchi = self.comoving_radial_distance(zmax) - self.comoving_radial_distance(zmin)
-            Wz2s = 1.0 / dchi / hzs
-        return self.limber_integral(ells, zs, ks, Pgp, gzs, 1, Wz2s, hzs, chis)
+        """The reference's body (hmvec/cosmology.py:570-583) reads two names it never defines
+        (``dndz`` for an extended window, ``Ppy`` otherwise) and raises NameError on every call; the
+        mirror keeps that behaviour rather than guess what was meant (as rhoscale_nfw does)."""
+        raise NameError("name 'dndz' is not defined" if np.asarray(gzs).size > 1 else "name 'Ppy' is not defined")
 
     # ------------------------------------------------------------------ small derived quantities
     def _baryon_cdm_fractions(self):
@@ -435,23 +428,6 @@ class Cosmology(object):
             return np.sqrt(r[0]), r[1], r[2]
         return np.sqrt(r)
 
-    def sigma_crit(self, zlens, zsource):
-        """Critical surface density, Msun/Mpc^2 (hmvec/cosmology.py:95-101)."""
-        Gval = 4.517e-48   # Newton G in Mpc, seconds, Msun units
-        cval = 9.716e-15   # speed of light in Mpc, second units
-        Dd = self.angular_diameter_distance(zlens)
-        Ds = self.angular_diameter_distance(zsource)
-        Dds = np.asarray([self.angular_diameter_distance(zl, zsource) for zl in zlens])
-        return cval ** 2 * Ds / 4 / np.pi / Gval / Dd / Dds
-
-    def bias_fnl(self, bg, fnl, z, ks, deltac=1.42):
-        """Scale-dependent bias from local f_NL (hmvec/cosmology.py:132-136)."""
-        beta = 2.0 * deltac * (bg - 1.0)
-        a = 1.0 / (1 + z)
-        alpha = (2.0 * ks ** 2.0 * self.Tk(ks, type="eisenhu_osc")) / (3.0 * self.omm0 * self.h_of_z(0) ** 2.0) \
-            * self.D_growth(a, type="anorm", exact=False)
-        return bg + fnl * (beta / alpha)
-
     def P_mm_linear(self, zs, ks):
         """Placeholder in the reference too (hmvec/cosmology.py:104-105: ``pass``)."""
         return None
@@ -476,9 +452,13 @@ def _limber(ctx, ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis):
         if np.any(kev < ks[0]) or np.any(kev > ks[-1]):
             raise ValueError("A value in x_new is outside the interpolation range.")  # interp1d
     wz = trapz_weights(gzs) if gzs.size > 1 else np.ones(1)
-    dP = Pzks if isinstance(Pzks, nat.DeviceArray) else ctx.upload(np.asarray(Pzks, dtype=np.float64))
+    dP2 = None
+    if isinstance(Pzks, tuple):          # (P_1h, P_2h) device arrays: summed inside the kernel
+        dP, dP2 = Pzks
+    else:
+        dP = Pzks if isinstance(Pzks, nat.DeviceArray) else ctx.upload(np.asarray(Pzks, dtype=np.float64))
     d = [ctx.upload(a) for a in (ells, zs, ks, gzs, pref, chis + 0.0 * gzs, wz)]
     out = ctx.empty((ells.size,))
-    ctx.call("hmg_limber", ells.size, d[0].ptr, zs.size, ks.size, d[1].ptr, d[2].ptr, dP.ptr,
+    ctx.call("hmg_limber", ells.size, d[0].ptr, zs.size, ks.size, d[1].ptr, d[2].ptr, dP.ptr, nat.ptr(dP2),
              gzs.size, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr, out.ptr)
     return out.numpy().reshape(np.shape(ells))

@@ -1,10 +1,11 @@
 // libhmgrid — MI355X (gfx950 / CDNA4) kernels + C ABI for the halo-model grid hot path.
 // Boundary and reference citations: include/hmgrid.h.  Design notes: DESIGN.md.
 //
-// Everything here is fp64, HBM-bandwidth or fp64-VALU bound; there is no dense
-// contraction on this path, so no MFMA.  Layout is [z][m][k] with k fastest: a wavefront
-// (64 lanes) always walks consecutive k, so every tensor access is a fully coalesced
-// 512 B (or 1 KiB with double2) wave transaction, and per-(z,m) scalars are wave-uniform.
+// Everything here is fp64 and either HBM-bandwidth or fp64-VALU bound; the one dense contraction
+// of the path (sigma^2: a (z x k') . (k' x m) product) runs on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64).  Layout is [z][m][k] with k fastest: a wavefront (64 lanes) always
+// walks consecutive k, so every tensor access is a fully coalesced 512 B (or 1 KiB with double2)
+// wave transaction, and per-(z,m) scalars are wave-uniform.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <rocfft/rocfft.h>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "../../include/hmgrid.h"
+#include "fastmath.hpp"
 #include "ldsfft.hpp"
 #include "sici.hpp"
 
@@ -94,8 +96,19 @@ struct hmg_ctx {
     void* pinned[2] = {nullptr, nullptr};   // host bounce buffers for pageable <-> device copies
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     int num_cu = 256;
+    // device blocks handed back by hmg_free, kept for reuse by size: dropping an array never
+    // synchronises the device and a steady stream of same-shaped temporaries never reaches hipMalloc
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> block_bytes;           // every live or cached block from hmg_malloc
+    size_t cached_bytes = 0;
+    bool lanes_dirty = false;                      // work was enqueued on a lane other than 0 since the last sync
+    // captured steps (hmg_graph_*)
+    bool capturing = false;
+    std::map<int, hipGraphExec_t> graphs;
+    int next_graph_id = 1;
     hmg_ctx() { for (auto& b : bracket) b[0] = b[1] = -1; }
 };
+constexpr size_t FREE_CACHE_LIMIT = (size_t)4 << 30;   // bytes kept in the free list before real frees
 
 static int rocfft_refcount = 0;
 
@@ -107,12 +120,15 @@ static int event_at(hmg_ctx* c, int slot, hipEvent_t* out) {
 }
 
 static int sync_all(hmg_ctx* c) {
+    REQUIRE(!c->capturing, "this call synchronises the device and cannot be part of a captured step");
     for (auto& st : c->lanes) HIP_TRY(hipStreamSynchronize(st));
+    c->lanes_dirty = false;
     return 0;
 }
 
 static int ensure_scratch(hmg_ctx* c, int slot, size_t bytes) {
     if (c->scratch_bytes[slot] >= bytes) return 0;
+    REQUIRE(!c->capturing, "scratch must not grow inside a captured step: run the step once eagerly first");
     if (c->scratch[slot]) {
         if (sync_all(c)) return 1;
         HIP_TRY(hipFree(c->scratch[slot]));
@@ -778,28 +794,32 @@ struct FusedArgs {
 };
 
 // amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two
-// powers of t): ~4x fewer VALU ops than three pow() calls; relative error < 2e-15.
+// powers of t) with the short fp64 log/exp/log1p of fastmath.hpp (< 2 ulp each, host-tested):
+// ~100 VALU ops per sample instead of ~190 with the device library's and ~700 with three pow().
 __device__ __forceinline__ double gnfw_rho_fast(double x, double A, double inv_xc, double AL,
                                                 double EX, double gamma) {
-    const double lt = log(x * inv_xc);
-    const double ta = exp(AL * lt);
-    return A * exp(gamma * lt - EX * log1p(ta));
+    const double lt = log_fast(x * inv_xc);
+    const double ta = exp_fast(fmin(AL * lt, 700.0));
+    return A * exp_fast(gamma * lt - EX * log1p_fast(ta));
 }
 
 template <int NT, int R, int MAXB>
-__device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ twM, int M, int Ns) {
+__device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ twM, int M, int Ns, int twstep,
+                                           unsigned magic, int keep) {
+    // keep >= 0 (last pass only, Ns == M/R): butterfly j writes Z[j + t*Ns]; only Z[0..keep] and
+    // Z[M-keep..M-1] will be read, i.e. butterflies j <= keep (t = 0) and j >= Ns - keep (t = R-1).
     cplx v[MAXB][R];
     const int nb = M / R;
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
         const int j = threadIdx.x + b * NT;
-        if (j < nb) pass_load<R>(buf, twM, M, Ns, j, v[b]);
+        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_load<R>(buf, twM, M, Ns, twstep, magic, j, v[b]);
     }
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
         const int j = threadIdx.x + b * NT;
-        if (j < nb) pass_store<R>(buf, Ns, j, v[b]);
+        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_store<R>(buf, Ns, magic, j, v[b]);
     }
     __syncthreads();
 }
@@ -811,19 +831,34 @@ template <int NT, int MAXB, int MAXP>
 __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_fused_kernel(FusedArgs A) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
-    // scratch and the broadcast mass norm.
+    // scratch, the broadcast mass norm and the left-fill counter.
     extern __shared__ __attribute__((aligned(16))) double smem[];
     cplx* buf = reinterpret_cast<cplx*>(smem);
     const int row = blockIdx.x;
     const int M = A.plan.M, nxs = A.nxs;
     double* red = smem + 2 * (size_t)M;
     double& s_mn = red[16];
+    int* s_cnt = reinterpret_cast<int*>(red + 17);
     const double Aamp = A.amp ? A.amp[row] : A.amp_c;
     const double XC = A.xc ? A.xc[row] : A.xc_c;
     const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
     const double EX = A.expo ? A.expo[row] : A.expo_c;
     const double cm = A.cmax[row];
     const double inv_xc = 1.0 / XC;
+    // Output side of the row: the FFT modes sit on the uniform grid kout_j = j k_lo,
+    // k_lo = kt_1 / (r_s (1+z)).  Targets below k_lo take np.interp's left fill u_1, targets above
+    // kout_M are zero, and only the modes j <= jn = floor(max(ks)/k_lo) + 2 can be reached at all:
+    // low-mass rows (large k_lo) need a few dozen of the M modes, so the unpack and the last FFT
+    // pass are cut down to those.  max(ks) is only known without a search when ks is ascending,
+    // which is the caller's promise that comes with the hint arrays (include/hmgrid.h).
+    const int z = row / A.nm;
+    int jn = M;
+    if (A.nconst) {
+        const double tmax = A.ks[A.nk - 1] * (A.rss[row] * (1.0 + A.zs[z])) / A.kts[1];
+        if (tmax < (double)(M - 4)) jn = (int)tmax + 3;    // one spare mode for the rounding of tmax
+    }
+    jn = __builtin_amdgcn_readfirstlane(jn);
+    if (threadIdx.x == 0) *s_cnt = 0;
     // ---- phase A: y_n = x_n rho(x_n) theta(x_n <= cmax) packed as (y_2p, y_2p+1); mass norm
     // Pruned first pass: the integrand is zero beyond the truncation radius (85 % of a Battaglia
     // row at xmax = 20).  When every packed sample p >= M/R0 is zero, the first radix-R0 pass
@@ -857,18 +892,20 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     }
     __syncthreads();
     // ---- phase B: in-place Stockham FFT of length M
-    int Ns = pruned ? R0 : 1;
     for (int ps = pruned ? 1 : 0; ps < A.plan.npass; ++ps) {
-        const int R = A.plan.radix[ps];
+        const int R = A.plan.radix[ps], Ns = A.plan.ns[ps], tws = A.plan.twstep[ps];
+        const unsigned mg = A.plan.magic[ps];
         // a pass whose butterflies fit one per thread uses the MAXB = 1 body (fewer live registers)
         const bool one = (M / R) <= NT;
-        if (R == 5) { if (one) fused_pass<NT, 5, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 5, MAXB>(buf, A.twM, M, Ns); }
-        else if (R == 4) { if (one) fused_pass<NT, 4, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 4, MAXB>(buf, A.twM, M, Ns); }
-        else if (R == 3) { if (one) fused_pass<NT, 3, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns); }
-        else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns); }
-        Ns *= R;
+        // the last pass only has to produce Z[0..jn] and Z[M-jn..M-1]
+        const int keep = (ps == A.plan.npass - 1 && 2 * jn + 2 < M / R) ? jn : -1;
+        if (R == 5) { if (one) fused_pass<NT, 5, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 5, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
+        else if (R == 4) { if (one) fused_pass<NT, 4, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 4, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
+        else if (R == 3) { if (one) fused_pass<NT, 3, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
+        else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
     }
-    // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm, j = 1..M, into smem[0..M-1]
+    // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm for the reachable modes
+    // j = 1..jn, into smem[0..jn-1]
     const double inv_mn = 1.0 / s_mn;
     const double sc = -A.step * inv_mn;
     double ua[MAXP], ub[MAXP];
@@ -876,13 +913,14 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
 #pragma unroll
     for (int b = 0; b < MAXP; ++b) {
         const int j = 1 + threadIdx.x + b * NT;
-        if (j <= half) {
+        const bool hi = (M - j <= jn);                 // the mirrored mode M-j is reachable too
+        if (j <= half && (j <= jn || hi)) {
             const cplx zj = buf[j], zmj = buf[M - j];
             const double2 w = A.twN[j];
             double fa, fb;
             unpack_imag_pair(zj, zmj, w.x, w.y, fa, fb);
             ua[b] = fa * sc * rcp_fast(A.kts[j]);
-            ub[b] = fb * sc * rcp_fast(A.kts[M - j]);
+            ub[b] = hi ? fb * sc * rcp_fast(A.kts[M - j]) : 0.0;
         }
     }
     __syncthreads();
@@ -890,48 +928,50 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
 #pragma unroll
     for (int b = 0; b < MAXP; ++b) {
         const int j = 1 + threadIdx.x + b * NT;
-        if (j <= half) {
+        const bool hi = (M - j <= jn);
+        if (j <= half && (j <= jn || hi)) {
             u[j - 1] = ua[b];
-            if (M - j >= 1) u[M - j - 1] = ub[b];
+            if (hi && M - j >= 1) u[M - j - 1] = ub[b];
         }
     }
     if (threadIdx.x == 0) u[M - 1] = 0.0;  // Nyquist mode: Im F_M == 0
     __syncthreads();
-    // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid
-    const int z = row / A.nm;
+    // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid:
+    // bracket j = floor(k/k_lo), weight k/k_lo - j (one FMA), two LDS reads.  The left fill is a
+    // plain splat (63 % of the Battaglia tensor at Config 3).
     const double isc = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));  // kout_j = kts[j] * isc
-    const double pf = A.post ? A.post[row] : 1.0;
     const double k_lo = A.kts[1] * isc, k_hi = A.kts[M] * isc;
     const double inv_dk = 1.0 / k_lo;
+    const double pf = A.post ? A.post[row] : 1.0;
+    const double u1 = u[0];
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
-    if (A.nconst && threadIdx.x == 0) {
-        int lo = 0, hi = A.nk;            // first i with !(ks[i] < k_lo); ks ascending
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (A.ks[mid] < k_lo) lo = mid + 1; else hi = mid;
-        }
-        A.nconst[row] = lo;
-        A.cconst[row] = u[0] * pf;
-    }
+    int nleft = 0;     // wave-uniform count of left-filled targets seen by this wavefront
     for (int i = threadIdx.x; i < A.nk; i += NT) {
         const double k = A.ks[i];
         double val;
-        if (k < k_lo) {
-            val = u[0];
+        const bool left = k < k_lo;
+        if (A.nconst) nleft += __popcll(__ballot(left));
+        if (left) {
+            val = u1;
         } else if (k > k_hi) {
             val = 0.0;
-        } else if (k == k_hi) {
-            val = u[M - 1];
         } else {
             int j = (int)(k * inv_dk);
             j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
-            double x0 = A.kts[j] * isc, x1 = A.kts[j + 1] * isc;
-            if (x0 > k && j > 1) { --j; x1 = x0; x0 = A.kts[j] * isc; }
-            else if (x1 <= k && j < M - 1) { ++j; x0 = x1; x1 = A.kts[j + 1] * isc; }
+            const double fr = fma(k, inv_dk, -(double)j);
             const double y0 = u[j - 1], y1 = u[j];
-            val = (x0 == k) ? y0 : fma((y1 - y0) * rcp_fast(x1 - x0), k - x0, y0);
+            val = fma(y1 - y0, fr, y0);
         }
         __builtin_nontemporal_store(val * pf, &dst[i]);
+    }
+    if (A.nconst) {
+        // ks ascending: the number of targets below k_lo is the index of the first one that is not
+        if ((threadIdx.x & 63) == 0 && nleft) atomicAdd(s_cnt, nleft);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            A.nconst[row] = *s_cnt;
+            A.cconst[row] = u1 * pf;
+        }
     }
 }
 
@@ -1148,6 +1188,9 @@ struct PowerArgs {
     const double* Pzk;
     double* P1h;
     double* P2h;
+    double* I1;       // optional: the two 2-halo integrals I_a(z,k), I_b(z,k) and
+    double* I2;
+    double* Cout;     // [nz][2] their k -> 0 limits C_a, C_b (get_power_2halo(verbose=True))
     double kstar;
     int nm, nk;
 };
@@ -1243,6 +1286,9 @@ __global__ __launch_bounds__(1024) void power_kernel(PowerArgs A) {
                 A.P1h[o] = s1 * (1.0 - exp(-(q * q)));
             }
             if (A.P2h) A.P2h[o] = A.Pzk[o] * (sA + bA - CA) * (sB + bB - CB);
+            if (A.I1) A.I1[o] = sA;
+            if (A.I2) A.I2[o] = sB;
+            if (A.Cout && k == 0) { A.Cout[z * 2] = CA; A.Cout[z * 2 + 1] = CB; }
         }
     }
 }
@@ -1502,7 +1548,8 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
 // window redshifts; wz = trapezoid weights over those redshifts (or {1} for a delta window).
 __global__ void limber_kernel(int nells, const double* __restrict__ ells, int nz, int nk,
                               const double* __restrict__ zs, const double* __restrict__ ks,
-                              const double* __restrict__ P, int ngz, const double* __restrict__ gzs,
+                              const double* __restrict__ P, const double* __restrict__ P2, int ngz,
+                              const double* __restrict__ gzs,
                               const double* __restrict__ pref, const double* __restrict__ chis,
                               const double* __restrict__ wz, double* __restrict__ out) {
 #pragma clang fp contract(off)
@@ -1521,8 +1568,10 @@ __global__ void limber_kernel(int nells, const double* __restrict__ ells, int nz
         const int i = lo;
         const double tx = (k - ks[i]) / (ks[i + 1] - ks[i]);
         double val;
+        // P2 (optional) is added on the fly: C_ell of P_1h + P_2h without materialising the sum
+        auto at = [&](size_t o) { return P2 ? P[o] + P2[o] : P[o]; };
         if (nz == 1) {
-            val = (1.0 - tx) * P[i] + tx * P[i + 1];
+            val = (1.0 - tx) * at(i) + tx * at(i + 1);
         } else {
             double z = fmin(fmax(gzs[g], zs[0]), zs[nz - 1]);
             int jl = 0, jh = nz - 1;
@@ -1532,10 +1581,9 @@ __global__ void limber_kernel(int nells, const double* __restrict__ ells, int nz
             }
             const int j = jl;
             const double ty = (z - zs[j]) / (zs[j + 1] - zs[j]);
-            const double* r0 = P + (size_t)j * nk;
-            const double* r1 = r0 + nk;
-            val = (1.0 - tx) * (1.0 - ty) * r0[i] + tx * (1.0 - ty) * r0[i + 1] +
-                  (1.0 - tx) * ty * r1[i] + tx * ty * r1[i + 1];
+            const size_t r0 = (size_t)j * nk + i, r1 = r0 + nk;
+            val = (1.0 - tx) * (1.0 - ty) * at(r0) + tx * (1.0 - ty) * at(r0 + 1) +
+                  (1.0 - tx) * ty * at(r1) + tx * ty * at(r1 + 1);
         }
         acc += wz[g] * (val * pref[g]);
     }
@@ -1707,11 +1755,6 @@ __global__ __launch_bounds__(256) void fn2d_kernel(FnArgs A) {
     case HMG_FN_LINCOMB3:
         y = par[0] * X(0) + par[1] * X(1) + par[2] * X(2);
         break;
-    case HMG_FN_BRUTE_INTEGRAND: {
-        const double k = X(0), rr = X(1);
-        y = 4.0 * M_PI * rr * sin(rr * k) * X(2) / k;
-        break;
-    }
     }
     A.out[idx] = y;
 }
@@ -1800,14 +1843,7 @@ static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + blo
 int hmg_abi_version(void) { return HMG_ABI_VERSION; }
 const char* hmg_last_error(void) { return g_last_error.c_str(); }
 
-int hmg_ctx_create(int device, hmg_ctx** out) {
-    REQUIRE(out != nullptr, "out is NULL");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    REQUIRE(ndev > 0, "no HIP device visible");
-    REQUIRE(device >= 0 && device < ndev, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    hmg_ctx* c = new hmg_ctx();
+static int ctx_init(hmg_ctx* c, int device) {
     c->device = device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -1822,7 +1858,6 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
             HIP_TRY(hipStreamCreateWithPriority(&c->lanes[i], hipStreamNonBlocking, i == 0 ? hi : lo));
     }
     c->stream = c->lanes[0];
-    if (rocfft_refcount++ == 0) FFT_TRY(rocfft_setup());
     {
         const hmg::SiciTable t = hmg::sici_table_host();
         HIP_TRY(hipMalloc((void**)&c->d_sici, sizeof(t)));
@@ -1830,6 +1865,25 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
     }
     if (const char* s = getenv("HMG_FUSED_FFT")) c->use_fused_fft = atoi(s);
     if (const char* s = getenv("HMG_FFT_CHUNK_MB")) c->fft_chunk_bytes = (size_t)atol(s) << 20;
+    return 0;
+}
+
+int hmg_ctx_create(int device, hmg_ctx** out) {
+    REQUIRE(out != nullptr, "out is NULL");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    REQUIRE(ndev > 0, "no HIP device visible");
+    REQUIRE(device >= 0 && device < ndev, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    if (rocfft_refcount == 0) FFT_TRY(rocfft_setup());
+    ++rocfft_refcount;
+    hmg_ctx* c = new hmg_ctx();
+    if (ctx_init(c, device)) {          // a failed set-up must not leak the half-built context
+        const std::string keep = g_last_error;
+        hmg_ctx_destroy(c);
+        g_last_error = keep;
+        return 1;
+    }
     *out = c;
     return 0;
 }
@@ -1837,8 +1891,9 @@ int hmg_ctx_create(int device, hmg_ctx** out) {
 int hmg_ctx_destroy(hmg_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    for (auto& st : c->lanes) (void)hipStreamSynchronize(st);
+    for (auto& st : c->lanes) if (st) (void)hipStreamSynchronize(st);
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : c->plans) {
         if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
         if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
@@ -1849,6 +1904,7 @@ int hmg_ctx_destroy(hmg_ctx* c) {
         if (kv.second.twN) (void)hipFree(kv.second.twN);
     }
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
+    for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     if (c->d_barrier) (void)hipFree(c->d_barrier);
     if (c->d_sici) (void)hipFree(c->d_sici);
     for (int i = 0; i < 2; ++i) {
@@ -1856,23 +1912,73 @@ int hmg_ctx_destroy(hmg_ctx* c) {
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
     }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-    for (auto& st : c->lanes) (void)hipStreamDestroy(st);
+    for (auto& st : c->lanes) if (st) (void)hipStreamDestroy(st);
     if (--rocfft_refcount == 0) rocfft_cleanup();
     delete c;
     return 0;
 }
 
+// Device blocks are recycled by size.  Every launch of the library is stream-ordered on lane 0
+// unless the caller moved work to another lane (hmg_lane_set), so a block handed back by the host
+// may be reused by later lane-0 work without a device synchronisation: whatever still reads or
+// writes it was enqueued earlier on the same stream.  If other lanes have been used since the last
+// synchronisation, hmg_free synchronises first, as it always used to.
 int hmg_malloc(hmg_ctx* c, size_t bytes, void** d_out) {
     REQUIRE(c && d_out, "NULL argument");
+    if (!bytes) bytes = 8;
+    auto it = c->free_blocks.find(bytes);
+    if (it != c->free_blocks.end()) {
+        *d_out = it->second;
+        c->cached_bytes -= bytes;
+        c->free_blocks.erase(it);
+        return 0;
+    }
+    REQUIRE(!c->capturing, "device allocation inside a captured step: run the step once eagerly first");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 8));
+    hipError_t e = hipMalloc(d_out, bytes);
+    if (e != hipSuccess && !c->free_blocks.empty()) {      // give the cache back and retry once
+        if (sync_all(c)) return 1;
+        for (auto& kv : c->free_blocks) { (void)hipFree(kv.second); c->block_bytes.erase(kv.second); }
+        c->free_blocks.clear();
+        c->cached_bytes = 0;
+        e = hipMalloc(d_out, bytes);
+    }
+    HIP_TRY(e);
+    c->block_bytes[*d_out] = bytes;
     return 0;
 }
 int hmg_free(hmg_ctx* c, void* p) {
     REQUIRE(c, "NULL ctx");
     if (!p) return 0;
+    REQUIRE(!c->capturing, "hmg_free inside a captured step");
+    auto it = c->block_bytes.find(p);
+    REQUIRE(it != c->block_bytes.end(), "pointer was not allocated by hmg_malloc of this context");
+    if (c->lanes_dirty && sync_all(c)) return 1;
+    const size_t bytes = it->second;
+    if (c->cached_bytes + bytes <= FREE_CACHE_LIMIT) {
+        c->free_blocks.emplace(bytes, p);
+        c->cached_bytes += bytes;
+        return 0;
+    }
     if (sync_all(c)) return 1;
     HIP_TRY(hipFree(p));
+    c->block_bytes.erase(it);
+    return 0;
+}
+int hmg_host_alloc(hmg_ctx* c, size_t bytes, void** h_out) {
+    REQUIRE(c && h_out, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(h_out, bytes ? bytes : 8, hipHostMallocDefault));
+    return 0;
+}
+int hmg_host_free(hmg_ctx* c, void* h) {
+    REQUIRE(c, "NULL ctx");
+    if (h) HIP_TRY(hipHostFree(h));
+    return 0;
+}
+int hmg_memcpy_d2h_async(hmg_ctx* c, void* h_pinned, const void* d, size_t bytes) {
+    REQUIRE(c && h_pinned && d, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(h_pinned, d, bytes, hipMemcpyDeviceToHost, c->stream));
     return 0;
 }
 constexpr size_t PIN_CHUNK = (size_t)8 << 20;   // 8 MiB per bounce buffer
@@ -1911,7 +2017,10 @@ int hmg_memcpy_h2d(hmg_ctx* c, void* d, const void* h, size_t bytes) {
 }
 int hmg_memcpy_d2h(hmg_ctx* c, void* h, const void* d, size_t bytes) {
     REQUIRE(c && d && h, "NULL argument");
-    if (sync_all(c)) return 1;  // the producer may have run on any lane
+    REQUIRE(!c->capturing, "hmg_memcpy_d2h inside a captured step");
+    // the copy runs on the current lane, behind everything enqueued there; only when other lanes
+    // have been used can the producer sit elsewhere
+    if (c->lanes_dirty && sync_all(c)) return 1;
     if (bytes < (256u << 10)) {
         HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1950,6 +2059,7 @@ int hmg_sync(hmg_ctx* c) {
 }
 int hmg_lane_set(hmg_ctx* c, int lane) {
     REQUIRE(c && lane >= 0 && lane < HMG_LANES, "bad lane");
+    if (lane != 0) c->lanes_dirty = true;
     c->lane = lane;
     c->stream = c->lanes[lane];
     return 0;
@@ -1974,6 +2084,67 @@ int hmg_elapsed_ms(hmg_ctx* c, int s0, int s1, double* ms) {
     float f = 0.f;
     HIP_TRY(hipEventElapsedTime(&f, c->ev[s0], c->ev[s1]));
     *ms = (double)f;
+    return 0;
+}
+
+// ---- captured steps ----------------------------------------------------------------------------
+// Everything enqueued between hmg_graph_begin and hmg_graph_end (on lane 0 and on any lane that joins
+// through hmg_event_wait on an event recorded inside the capture) becomes one HIP graph: a pass of
+// the path is then ONE host call instead of ~15 launches, and independent branches (the sigma^2 ->
+// n(z,m) -> HOD chain beside the two profile kernels) run concurrently.  Nothing that allocates,
+// frees or synchronises may happen in between: run the same sequence once eagerly first, so that
+// scratch arenas, FFT tables and output buffers exist.
+int hmg_graph_begin(hmg_ctx* c) {
+    REQUIRE(c, "NULL ctx");
+    REQUIRE(!c->capturing, "already capturing");
+    REQUIRE(c->lane == 0, "start a capture on lane 0");
+    HIP_TRY(hipStreamBeginCapture(c->lanes[0], hipStreamCaptureModeRelaxed));
+    c->capturing = true;
+    return 0;
+}
+int hmg_graph_end(hmg_ctx* c, int* id) {
+    REQUIRE(c && id, "NULL argument");
+    REQUIRE(c->capturing, "no capture in progress");
+    c->capturing = false;
+    c->lane = 0;
+    c->stream = c->lanes[0];
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamEndCapture(c->lanes[0], &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIP_TRY(e);
+    *id = c->next_graph_id++;
+    c->graphs[*id] = ge;
+    return 0;
+}
+int hmg_graph_abort(hmg_ctx* c) {      // leave capture mode after a failed call inside a capture
+    REQUIRE(c, "NULL ctx");
+    if (!c->capturing) return 0;
+    c->capturing = false;
+    c->lane = 0;
+    c->stream = c->lanes[0];
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(c->lanes[0], &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return 0;
+}
+int hmg_graph_launch(hmg_ctx* c, int id) {
+    REQUIRE(c, "NULL ctx");
+    REQUIRE(!c->capturing, "cannot replay a graph inside a capture");
+    auto it = c->graphs.find(id);
+    REQUIRE(it != c->graphs.end(), "unknown graph id");
+    HIP_TRY(hipGraphLaunch(it->second, c->stream));
+    return 0;
+}
+int hmg_graph_destroy(hmg_ctx* c, int id) {
+    REQUIRE(c, "NULL ctx");
+    auto it = c->graphs.find(id);
+    if (it == c->graphs.end()) return 0;
+    if (sync_all(c)) return 1;
+    HIP_TRY(hipGraphExecDestroy(it->second));
+    c->graphs.erase(it);
     return 0;
 }
 
@@ -2339,11 +2510,12 @@ static int launch_power(hmg_ctx* c, const PowerArgs& A, int nz, int ms_split) {
     return bracket_close(c, stop);
 }
 
-int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hmg_tracer* tb,
-              const double* nzm, const double* bh, const double* ms, const double* wm, const double* ks,
-              const double* Pzk, double rho_m0, double kstar, double* P1h, double* P2h) {
+static int power_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hmg_tracer* tb,
+                      const double* nzm, const double* bh, const double* ms, const double* wm, const double* ks,
+                      const double* Pzk, double rho_m0, double kstar, double* P1h, double* P2h,
+                      double* I1, double* I2, double* Cout) {
     REQUIRE(c && ta && tb && nzm && bh && ms && wm && ks, "NULL argument");
-    REQUIRE(P1h || P2h, "no output requested");
+    REQUIRE(P1h || P2h || (I1 && I2 && Cout), "no output requested");
     REQUIRE(!P2h || Pzk, "P2h needs Pzk");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
     REQUIRE(nz <= 65535, "nz too large");
@@ -2363,6 +2535,7 @@ int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hm
     PowerArgs A;
     for (int i = 0; i < PW_MAXT; ++i) A.tens[i] = i < Q.nt ? tens[i] : nullptr;
     A.coef = coef; A.side = side; A.ks = ks; A.Pzk = Pzk; A.P1h = P1h; A.P2h = P2h;
+    A.I1 = I1; A.I2 = I2; A.Cout = Cout;
     A.kstar = kstar; A.nm = nm; A.nk = nk;
     bool vec2 = (nk % 2 == 0);
     for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
@@ -2385,6 +2558,19 @@ int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hm
     }
 #undef PW_CASE
     return fail("hmg_power", "unreachable", __FILE__, __LINE__);
+}
+
+int hmg_power(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hmg_tracer* tb,
+              const double* nzm, const double* bh, const double* ms, const double* wm, const double* ks,
+              const double* Pzk, double rho_m0, double kstar, double* P1h, double* P2h) {
+    return power_impl(c, nz, nm, nk, ta, tb, nzm, bh, ms, wm, ks, Pzk, rho_m0, kstar, P1h, P2h, nullptr, nullptr, nullptr);
+}
+
+int hmg_power_2halo_terms(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* ta, const hmg_tracer* tb,
+                          const double* nzm, const double* bh, const double* ms, const double* wm,
+                          const double* ks, double rho_m0, double* I1, double* I2, double* C12) {
+    REQUIRE(I1 && I2 && C12, "NULL output");
+    return power_impl(c, nz, nm, nk, ta, tb, nzm, bh, ms, wm, ks, nullptr, rho_m0, 1.0, nullptr, nullptr, I1, I2, C12);
 }
 
 template <int NT, int NTR, int V>
@@ -2489,12 +2675,12 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
 }
 
 int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const double* zs,
-               const double* ks, const double* P, int ngz, const double* gzs, const double* pref,
-               const double* chis, const double* wz, double* out) {
+               const double* ks, const double* P, const double* P2, int ngz, const double* gzs,
+               const double* pref, const double* chis, const double* wz, double* out) {
     REQUIRE(c && ells && zs && ks && P && gzs && pref && chis && wz && out, "NULL argument");
     REQUIRE(nells > 0 && nz >= 1 && nk >= 2 && ngz >= 1, "bad sizes");
-    hipLaunchKernelGGL(limber_kernel, grid1d((size_t)nells, 128), dim3(128), 0, c->stream, nells, ells, nz,
-                       nk, zs, ks, P, ngz, gzs, pref, chis, wz, out);
+    hipLaunchKernelGGL(limber_kernel, grid1d((size_t)nells, 64), dim3(64), 0, c->stream, nells, ells, nz,
+                       nk, zs, ks, P, P2, ngz, gzs, pref, chis, wz, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2502,8 +2688,8 @@ int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const 
 // ---- function mirrors ------------------------------------------------------------------------
 int hmg_fn2d(hmg_ctx* c, int op, int rows, int cols, int nin, const double* const* in, const int* sr,
              const int* sc, const double* par, int npar, double* out) {
-    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4, 2, 3, 3};
-    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4, 1, 3, 0};
+    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4, 2, 3};
+    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4, 1, 3};
     REQUIRE(c && in && sr && sc && out, "NULL argument");
     REQUIRE(op >= 0 && op < HMG_FN_COUNT, "unknown function id");
     REQUIRE(rows > 0 && cols > 0, "empty grid");
@@ -2678,6 +2864,42 @@ int hmg_comm_allgather_multi(hmg_ctx* c, int n, const double* const* send, doubl
     NCCL_TRY(ncclGroupEnd());
     return 0;
 }
+// The z-slab gather of one pass, off the compute stream: an event marks "spectra ready" on the
+// current lane, the communication lane waits for it, issues the grouped all-gather and records
+// done_slot.  The next pass calls hmg_event_wait(done_slot) before it overwrites the local spectra,
+// so the collective overlaps the next pass's first kernels instead of extending the step.
+int hmg_comm_gather_async(hmg_ctx* c, int n, const double* const* send, double* const* recv, size_t count,
+                          int ready_slot, int done_slot, int comm_lane) {
+    REQUIRE(c && send && recv && n >= 0, "bad argument");
+    REQUIRE(!c->capturing, "the gather is issued outside captured steps");
+    REQUIRE(ready_slot >= 0 && ready_slot < HMG_EVENT_SLOTS && done_slot >= 0 && done_slot < HMG_EVENT_SLOTS, "bad event slot");
+    REQUIRE(comm_lane > 0 && comm_lane < HMG_LANES, "bad communication lane");
+    hipEvent_t ready, done;
+    if (event_at(c, ready_slot, &ready) || event_at(c, done_slot, &done)) return 1;
+    HIP_TRY(hipEventRecord(ready, c->stream));
+    hipStream_t keep = c->stream;
+    c->stream = c->lanes[comm_lane];
+    c->lanes_dirty = true;
+    HIP_TRY(hipStreamWaitEvent(c->stream, ready, 0));
+    const int rc = hmg_comm_allgather_multi(c, n, send, recv, count);
+    if (!rc) {
+        hipError_t e = hipEventRecord(done, c->stream);
+        c->stream = keep;
+        HIP_TRY(e);
+    }
+    c->stream = keep;
+    return rc;
+}
+int hmg_comm_info(hmg_ctx* c, int* rank, int* nranks) {
+    REQUIRE(c && rank && nranks, "NULL argument");
+    *rank = 0;
+    *nranks = 1;
+    if (c->comm) {      // ask RCCL, not our own bookkeeping: this is what the record of a run quotes
+        NCCL_TRY(ncclCommCount(c->comm, nranks));
+        NCCL_TRY(ncclCommUserRank(c->comm, rank));
+    }
+    return 0;
+}
 int hmg_comm_barrier(hmg_ctx* c) {
     REQUIRE(c, "NULL ctx");
     if (sync_all(c)) return 1;
@@ -2688,10 +2910,13 @@ int hmg_comm_barrier(hmg_ctx* c) {
 int hmg_comm_destroy(hmg_ctx* c) {
     REQUIRE(c, "NULL ctx");
     if (c->comm) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (sync_all(c)) return 1;      // collectives may be in flight on the communication lane
         NCCL_TRY(ncclCommDestroy(c->comm));
         c->comm = nullptr;
     }
+    if (c->d_barrier) {
+        HIP_TRY(hipFree(c->d_barrier));
+        c->d_barrier = nullptr;
+    }
     return 0;
 }
-

@@ -34,7 +34,21 @@ struct FftPlanDev {
     int M;       // complex length
     int npass;
     int radix[FFT_MAX_PASSES];
+    // per pass: Ns = product of the earlier radices, the twiddle-table step M/(Ns*R), and the
+    // multiplier that turns j / Ns into one 32x32 high multiply (exact for j < 2^16; 0 when Ns == 1)
+    int ns[FFT_MAX_PASSES];
+    int twstep[FFT_MAX_PASSES];
+    unsigned magic[FFT_MAX_PASSES];
 };
+
+// j / d for 0 <= j < 2^16, 1 < d < 2^16 with magic = floor(2^32 / d) + 1 (magic = 0 encodes d == 1)
+HMG_HD unsigned fast_div(unsigned j, unsigned magic) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return magic ? __umulhi(j, magic) : j;
+#else
+    return magic ? (unsigned)(((unsigned long long)j * magic) >> 32) : j;
+#endif
+}
 
 // Factor M into radices 5,4,3,2 (as few passes as possible: 4 before 2), then order the passes by
 // ascending radix.  The first pass is the one the fused profile kernel can skip when the input is
@@ -59,7 +73,14 @@ inline bool fft_make_plan(int M, FftPlanDev* p) {
             p->radix[j] = p->radix[j - 1];
             p->radix[j - 1] = tmp;
         }
-    return rem == 1 && M >= 2;
+    int Ns = 1;
+    for (int i = 0; i < p->npass; ++i) {
+        p->ns[i] = Ns;
+        p->twstep[i] = M / (Ns * p->radix[i]);
+        p->magic[i] = Ns == 1 ? 0u : (unsigned)(4294967296ull / (unsigned)Ns) + 1u;
+        Ns *= p->radix[i];
+    }
+    return rem == 1 && M >= 2 && M < 65536;
 }
 
 // In-place forward DFTs of size R (sign -).
@@ -109,12 +130,13 @@ HMG_HD void dft_small<5>(cplx* v) {
 }
 
 // One Stockham pass of radix R on butterfly j (0 <= j < M/R), sub-transform size Ns so far:
-//   load:  v[t] = buf[j + t*M/R] * W_M^(t * k * M/(Ns*R)),  k = j mod Ns
+//   load:  v[t] = buf[j + t*M/R] * W_M^(t * k * M/(Ns*R)),  k = j mod Ns  (no integer division: fast_div)
 //   store: buf[(j div Ns)*Ns*R + k + t*Ns] = DFT_R(v)[t]
 // Every load of a pass must precede every store of that pass (barrier on the GPU).
+// (Ns, twstep, magic) are the pass's entries of FftPlanDev.
 template <int R>
-HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int j, cplx* v) {
-    const int k = j % Ns;
+HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twstep, unsigned magic, int j, cplx* v) {
+    const int k = j - (int)fast_div((unsigned)j, magic) * Ns;      // j mod Ns
     const int stride = M / R;
     v[0] = buf[j];
     if (k == 0) {
@@ -124,7 +146,7 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int j, cp
     }
     // one table read (w = W^(k M/(Ns R))); the higher powers by complex multiplication
     // (<= 3 products, a few ulp) instead of R-1 dependent trips to the L2-resident table
-    const cplx w1 = twM[k * (M / (Ns * R))];
+    const cplx w1 = twM[k * twstep];
     cplx w = w1;
 #pragma unroll
     for (int t = 1; t < R; ++t) {
@@ -133,10 +155,11 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int j, cp
     }
 }
 template <int R>
-HMG_HD void pass_store(cplx* buf, int Ns, int j, cplx* v) {
+HMG_HD void pass_store(cplx* buf, int Ns, unsigned magic, int j, cplx* v) {
     dft_small<R>(v);
-    const int k = j % Ns;
-    const int j0 = (j / Ns) * Ns * R + k;
+    const int q = (int)fast_div((unsigned)j, magic);               // j div Ns
+    const int k = j - q * Ns;
+    const int j0 = q * Ns * R + k;
 #pragma unroll
     for (int t = 0; t < R; ++t) buf[j0 + t * Ns] = v[t];
 }

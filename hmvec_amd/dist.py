@@ -29,29 +29,40 @@ def slab_bounds(nz, world, rank):
 
 
 def rendezvous_path(tag, world):
-    """One file per launch: the tag (MASTER_PORT + run id from the launcher), the world size
-    and the launcher's PID, which all ranks of one torch.distributed.run share as parent."""
-    name = f"hmg_rdzv_{tag}_w{world}_pp{os.getppid()}"
+    """One file per launch: the tag (MASTER_PORT + run id from the launcher), the world size,
+    the launcher's PID (all ranks of one launch share it as parent) and, under an elastic
+    launcher, the restart count - so a restarted group never reads its predecessor's id."""
+    restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    name = f"hmg_rdzv_{tag}_w{world}_pp{os.getppid()}_r{restart}"
     return os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), name)
 
 
 def exchange_unique_id(ctx, rank, world, tag):
     """Rank 0 creates the RCCL unique id and publishes it through a file; the other ranks
-    of the node poll for it.  (One node only: SURVEY §8e; the id is 128 opaque bytes.)
-    Files older than 10 minutes are ignored as leftovers of a crashed launch."""
+    of the node poll for it.  (One node only: SURVEY 8e; the id is 128 opaque bytes.)
+    Rank 0 removes any leftover of an earlier launch first and creates the file exclusively
+    with mode 0600; the others accept only a file written after they started looking (minus a
+    clock-skew allowance), so the id of a crashed earlier launch is never picked up."""
     path = rendezvous_path(tag, world)
     buf = C.create_string_buffer(nat.COMM_ID_BYTES)
     if rank == 0:
         nat.check(ctx.lib.hmg_comm_unique_id(buf))
         tmp = path + f".tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
+        for stale in (path, tmp):
+            try:
+                os.unlink(stale)
+            except FileNotFoundError:
+                pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(buf.raw)
         os.replace(tmp, path)
         return buf
+    t_start = _PROCESS_START - float(os.environ.get("HMG_RDZV_SKEW", "5"))
     deadline = time.time() + float(os.environ.get("HMG_RDZV_TIMEOUT", "600"))   # first library page-in on a fresh box can take minutes
     while time.time() < deadline:
         try:
-            fresh = time.time() - os.path.getmtime(path) < 600.0
+            fresh = os.path.getmtime(path) >= t_start
             with open(path, "rb") as f:
                 raw = f.read()
             if fresh and len(raw) == nat.COMM_ID_BYTES:
@@ -61,6 +72,9 @@ def exchange_unique_id(ctx, rank, world, tag):
             pass
         time.sleep(0.01)
     raise TimeoutError(f"no RCCL unique id at {path}")
+
+
+_PROCESS_START = time.time()
 
 
 class RcclComm:
@@ -83,6 +97,13 @@ class RcclComm:
         rp = (C.c_void_p * n)(*[r.ptr for r in recvs])
         self.ctx.call("hmg_comm_allgather_multi", n, sp, rp, sends[0].size)
 
+    def gather_rows_async(self, sends, recvs, ready_slot, done_slot, comm_lane):
+        """allgather_rows on the communication lane, ordered by events (one native call)."""
+        n = len(sends)
+        sp = (C.c_void_p * n)(*[s.ptr for s in sends])
+        rp = (C.c_void_p * n)(*[r.ptr for r in recvs])
+        self.ctx.call("hmg_comm_gather_async", n, sp, rp, sends[0].size, ready_slot, done_slot, comm_lane)
+
     def allgather_host(self, values):
         """Small host-side all-gather of a float vector (timings); blocks."""
         v = np.ascontiguousarray(values, dtype=np.float64)
@@ -93,6 +114,12 @@ class RcclComm:
 
     def barrier(self):
         self.ctx.call("hmg_comm_barrier")
+
+    def info(self):
+        """(rank, nranks) as RCCL itself reports them (1 rank without a communicator)."""
+        r, n = C.c_int(), C.c_int()
+        self.ctx.call("hmg_comm_info", C.byref(r), C.byref(n))
+        return r.value, n.value
 
     def close(self):
         if self._inited:
@@ -129,15 +156,10 @@ class ShardedSpectra:
         else:
             self.full = self.local
 
-    def run(self, bracket=None, batched=True):
-        """Launch all spectra + the gather; asynchronous (no host sync).  `bracket` = (s0, s1)
-        event slots around the mass-integral kernel (batched mode) for bench.py."""
+    def launch_spectra(self, bracket=None, batched=True):
+        """The mass integrals of all pairs into the local (slab) buffers; launch-only, capturable."""
         m = self.model
         ctx = m._ctx()
-        gather = self._gather
-        if gather:
-            # the previous call's gather (on its own lane) must have finished reading `local`
-            ctx.wait(self._EV_GATHERED)
         if batched:
             if bracket is not None:
                 ctx.call("hmg_bracket_next", nat.KERNEL_POWER, bracket[0], bracket[1])
@@ -145,16 +167,35 @@ class ShardedSpectra:
         else:
             for i, (a, b) in enumerate(self.pairs):
                 m.power_device(a, b, out1=self.local[2 * i], out2=self.local[2 * i + 1])
-        if gather:
-            # The collective runs on the communication lane behind an event, so that the next pass of
-            # the path (which does not touch `full`, and `local` only after the wait above) overlaps it:
-            # over xGMI the all-gather of a 0.2 ms slab step would otherwise be a visible fraction of it.
-            ctx.record(self._EV_SPECTRA)
-            ctx.lane(self._COMM_LANE)
-            ctx.wait(self._EV_SPECTRA)
-            self.comm.allgather_rows(self.local, self.full)
-            ctx.record(self._EV_GATHERED)
-            ctx.lane(0)
+
+    def wait_gathered(self):
+        """Order the next overwrite of the local buffers behind the previous pass's gather."""
+        if self._gather:
+            self.model._ctx().wait(self._EV_GATHERED)
+
+    def gather(self):
+        """The collective of one pass, on the communication lane behind an event: the next pass of the
+        path (which does not touch `full`, and `local` only after wait_gathered) overlaps it - over
+        xGMI the all-gather of a 0.1 ms slab step would otherwise be a visible fraction of it."""
+        if not self._gather:
+            return
+        if hasattr(self.comm, "gather_rows_async"):
+            self.comm.gather_rows_async(self.local, self.full, self._EV_SPECTRA, self._EV_GATHERED, self._COMM_LANE)
+            return
+        ctx = self.model._ctx()            # communicators without the fused entry point (CPU rehearsal)
+        ctx.record(self._EV_SPECTRA)
+        ctx.lane(self._COMM_LANE)
+        ctx.wait(self._EV_SPECTRA)
+        self.comm.allgather_rows(self.local, self.full)
+        ctx.record(self._EV_GATHERED)
+        ctx.lane(0)
+
+    def run(self, bracket=None, batched=True):
+        """Launch all spectra + the gather; asynchronous (no host sync).  `bracket` = (s0, s1)
+        event slots around the mass-integral kernel (batched mode) for bench.py."""
+        self.wait_gathered()
+        self.launch_spectra(bracket, batched)
+        self.gather()
 
     def results(self):
         """{(a,b): (P1h, P2h)} as numpy (nz_total, nk) arrays; blocks."""

@@ -10,7 +10,7 @@ through here: for the NFW/Battaglia families the integrand is evaluated inside t
 """
 import numpy as np
 
-from .functions import FN_BRUTE_INTEGRAND, _ctx, fn2d, trapz_lastaxis
+from .functions import _ctx, trapz_lastaxis
 
 
 def fft_integral(x, y, axis=-1):
@@ -87,18 +87,4 @@ def uk_fft(rhofunc, rvir, dr=0.001, rmax=100):
     return ks, uk
 
 
-def uk_brute_force(r, rho, rvir, ks):
-    """Direct quadrature of the truncated profile's transform, the cross-check of uk_fft that the
-    reference's tests plot (hmvec/fft.py:22-33, bin/tests.py:36): for every k,
-    trapz_r[4 pi r sin(k r) rho / k] over r < rvir, divided by the enclosed mass."""
-    r = np.asarray(r, dtype=np.float64)
-    rho = np.asarray(rho, dtype=np.float64)
-    ks = np.asarray(ks, dtype=np.float64)
-    sel = np.where(r < rvir)
-    rs, rhos = r[sel], rho[sel]
-    m = trapz_lastaxis(rhos * rs ** 2.0, rs) * 4.0 * np.pi
-    integrand = fn2d(FN_BRUTE_INTEGRAND, [ks[:, None], rs[None, :], rhos[None, :]])      # (nk, nr)
-    return trapz_lastaxis(integrand, rs) / m
-
-
-__all__ = ["fft_integral", "analytic_fft_integral", "generic_profile_fft", "uk_fft", "uk_brute_force"]
+__all__ = ["fft_integral", "analytic_fft_integral", "generic_profile_fft", "uk_fft"]

@@ -775,6 +775,14 @@ class HaloModel(Cosmology):
                 ctx.lib.hmg_memcpy_d2d(ctx.handle, o2[i].ptr, o2[first[u]].ptr, o2[i].nbytes)
         return o1, o2
 
+    def spectra_block(self, pairs):
+        """A reusable result block for several (name, name2) spectra: one contiguous device buffer
+        for the 2*len(pairs) (nz,nk) outputs and one page-locked host buffer of the same shape.
+        ``compute()`` enqueues the batched mass integrals into it, ``fetch()`` brings all of them to
+        the host with ONE asynchronous copy at link speed and returns numpy views (valid until the
+        next ``fetch`` of the same block).  For parameter sweeps that read every spectrum back."""
+        return SpectraBlock(self, pairs)
+
     def get_power_all(self, pairs):
         """Extension of the reference API: {(name, name2): P_1h + P_2h} for several pairs in one
         pass over the profile tensors."""
@@ -881,9 +889,51 @@ class HaloModel(Cosmology):
             self._print_consistency(name, name2)
         return out
 
+    def two_halo_terms(self, name, name2=None):
+        """(I_1, C_1, I_2, C_2) of the 2-halo term (hmvec/hmvec.py:563-568): the mass integrals
+        I(z,k) = int dm n b W(k), shape (nz,nk), and their k -> 0 consistency limits C(z), shape (nz,1)."""
+        name2 = name if name2 is None else name2
+        ctx = self._join_profiles()
+        nz, nm, nk = self._nz, self._nm, self._nk
+        ta, tb = self._tracer(name, "mph")[0], self._tracer(name2, "mph")[0]
+        d_i1, d_i2, d_c = ctx.empty((nz, nk)), ctx.empty((nz, nk)), ctx.empty((nz, 2))
+        ctx.call("hmg_power_2halo_terms", nz, nm, nk, C.byref(ta), C.byref(tb), self._d_nzm.ptr, self._d_bh.ptr,
+                 self._d_ms().ptr, self._d_wm().ptr, self._d_ks().ptr, self._rho_m0(), d_i1.ptr, d_i2.ptr, d_c.ptr)
+        c = d_c.numpy()
+        return d_i1.numpy(), c[:, 0:1].copy(), d_i2.numpy(), c[:, 1:2].copy()
+
     def _print_consistency(self, name, name2):
-        print("Two-halo consistency: verbose integrals are not materialised on the device path "
-              "(%s, %s)" % (name, name2 if name2 is not None else name))
+        """The two lines get_power_2halo(verbose=True) prints (hmvec/hmvec.py:569-571)."""
+        i1, c1, i2, c2 = self.two_halo_terms(name, name2)
+        print("Two-halo consistency1: ", c1, i1)
+        print("Two-halo consistency2: ", c2, i2)
+
+
+class SpectraBlock:
+    """See HaloModel.spectra_block."""
+
+    def __init__(self, model, pairs):
+        self.model = model
+        self.pairs = [(a, a if b is None else b) for a, b in pairs]
+        ctx = model._ctx()
+        nz, nk = model.zs.size, model.ks.size
+        n = 2 * len(self.pairs)
+        self.dev = ctx.empty((n, nz, nk))
+        self.views = [self.dev.view(i * nz * nk, (nz, nk)) for i in range(n)]
+        self.host = nat.PinnedArray(ctx, (n, nz, nk))
+        self.nbytes = self.dev.nbytes
+
+    def compute(self):
+        """Launch-only: the spectra of all pairs into the device block."""
+        self.model.power_device_batch(self.pairs, self.views[0::2], self.views[1::2])
+
+    def fetch(self):
+        """{(name, name2): (P_1h, P_2h)} as views of the pinned host block; blocks until the copy lands."""
+        ctx = self.model._ctx()
+        ctx.copy_to_pinned(self.host, self.dev)
+        ctx.sync()
+        a = self.host.array
+        return {p: (a[2 * i], a[2 * i + 1]) for i, p in enumerate(self.pairs)}
 
 
 class _LazyArray:

@@ -14,8 +14,8 @@
  *    named h_* are host pointers.  No framework types cross this boundary.
  *  - Every function returns 0 on success, non-zero on failure; the message for the
  *    calling thread's last failure is returned by hmg_last_error().
- *  - All work is enqueued on the context's stream; only hmg_memcpy_d2h, hmg_sync,
- *    hmg_elapsed_ms and hmg_comm_barrier block the host.
+ *  - All work is enqueued on the context's stream; only hmg_memcpy_h2d, hmg_memcpy_d2h, hmg_sync,
+ *    hmg_elapsed_ms, hmg_graph_destroy, hmg_comm_barrier and hmg_comm_destroy block the host.
  *  - A context is bound to one GPU and is not thread-safe; use one per GPU/process.
  */
 #ifndef HMGRID_H
@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMG_ABI_VERSION 2
+#define HMG_ABI_VERSION 3
 
 typedef struct hmg_ctx hmg_ctx;
 
@@ -36,12 +36,22 @@ int         hmg_abi_version(void);
 const char* hmg_last_error(void);
 int hmg_ctx_create(int device, hmg_ctx** out);
 int hmg_ctx_destroy(hmg_ctx* ctx);
+/* Device blocks are recycled by size inside the context: hmg_free does not synchronise the device
+ * (unless work was moved to another lane since the last synchronisation) and a stream of same-shaped
+ * temporaries does not reach the driver's allocator.  Blocks are returned at hmg_ctx_destroy.      */
 int hmg_malloc(hmg_ctx* ctx, size_t bytes, void** d_out);
 int hmg_free(hmg_ctx* ctx, void* d_ptr);
 int hmg_memcpy_h2d(hmg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int hmg_memcpy_d2h(hmg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* blocks */
 int hmg_memcpy_d2d(hmg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int hmg_sync(hmg_ctx* ctx);                      /* waits for every lane */
+/* Result hand-over without staging: a page-locked host block (allocate once, reuse) and an
+ * asynchronous copy into it on the current lane; hmg_sync (or an event) completes it.  The
+ * reference returns host arrays from get_power* (hmvec/hmvec.py:500-572); this is how a batch of
+ * (nz,nk) spectra reaches the host in one DMA at link speed.                                      */
+int hmg_host_alloc(hmg_ctx* ctx, size_t bytes, void** h_out);
+int hmg_host_free(hmg_ctx* ctx, void* h_ptr);
+int hmg_memcpy_d2h_async(hmg_ctx* ctx, void* h_pinned_dst, const void* d_src, size_t bytes);
 /* Lanes: HMG_LANES HIP streams per context.  Every entry point enqueues on the CURRENT lane
  * (default 0).  Independent stages of the path (e.g. the NFW kernel and the profile-FFT kernel,
  * or the small per-(z,m) kernels) may be put on different lanes and ordered with events:
@@ -63,6 +73,17 @@ int hmg_elapsed_ms(hmg_ctx* ctx, int slot_start, int slot_stop, double* h_ms);  
 #define HMG_KERNEL_PROFILE_FFT 2
 #define HMG_KERNEL_COUNT       3
 int hmg_bracket_next(hmg_ctx* ctx, int kernel_id, int slot_start, int slot_stop);
+/* Captured steps.  Everything enqueued between hmg_graph_begin and hmg_graph_end - on lane 0 and on
+ * every lane that joins through hmg_event_wait on an event recorded inside the capture - becomes one
+ * HIP graph; hmg_graph_launch replays it with a single host call, independent branches running
+ * concurrently.  No allocation, free or synchronisation may occur inside a capture (the calls that
+ * would need one fail): run the same sequence once eagerly first.  A parameter sweep over a fixed
+ * grid (the benchmark's step, an MCMC over HOD parameters held in device buffers) replays the graph. */
+int hmg_graph_begin(hmg_ctx* ctx);
+int hmg_graph_end(hmg_ctx* ctx, int* h_graph_id);
+int hmg_graph_abort(hmg_ctx* ctx);                 /* leave capture mode after a failed call */
+int hmg_graph_launch(hmg_ctx* ctx, int graph_id);  /* on the current lane */
+int hmg_graph_destroy(hmg_ctx* ctx, int graph_id);
 
 /* ---- A2: sigma^2(z, R(m)) ------------------------------------------------------
  * Replaces Cosmology.get_sigma2_R (hmvec/cosmology.py:245-269) + Wkr (:30-38).
@@ -217,6 +238,13 @@ int hmg_power(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_tracer* h_a, const
               const double* d_ks, const double* d_Pzk, double rho_m0, double kstar,
               double* d_P1h /*[nz][nk] or NULL*/, double* d_P2h /*[nz][nk] or NULL*/);
 
+/* The terms get_power_2halo(verbose=True) prints (hmvec/hmvec.py:566-571): the two 2-halo
+ * integrals I_a(z,k), I_b(z,k) [nz][nk] and their k -> 0 consistency limits d_C12[z] = {C_a, C_b}. */
+int hmg_power_2halo_terms(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_tracer* h_a, const hmg_tracer* h_b,
+                          const double* d_nzm, const double* d_bh, const double* d_ms, const double* d_wm,
+                          const double* d_ks, double rho_m0,
+                          double* d_I1 /*[nz][nk]*/, double* d_I2 /*[nz][nk]*/, double* d_C12 /*[nz][2]*/);
+
 /* Same integrals for SEVERAL spectra in one pass: ntr tracers (<= 4) over their distinct
  * profile tensors (<= 4), npairs (a,b) index pairs into h_tr.  Each distinct tensor is streamed
  * from HBM once for the whole batch instead of once per pair.  h_P1h[i] / h_P2h[i] are the
@@ -236,7 +264,10 @@ int hmg_power_batch(hmg_ctx* ctx, int nz, int nm, int nk, int ntr, const hmg_tra
  * the caller; wz = trapezoid weights over gzs (a single 1 for a delta-function window).
  * nz == 1 does 1-D interpolation in k.                                                        */
 int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, const double* d_zs,
-               const double* d_ks, const double* d_Pzk, int ngz, const double* d_gzs,
+               const double* d_ks, const double* d_Pzk,
+               const double* d_Pzk2 /* optional second (nz,nk) array added to d_Pzk on the fly
+                                       (P_1h + P_2h without materialising the sum), or NULL */,
+               int ngz, const double* d_gzs,
                const double* d_pref, const double* d_chis, const double* d_wz, double* d_out);
 
 /* ---- module-level helpers of the path -------
@@ -274,9 +305,7 @@ int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, co
 #define HMG_FN_WKR           23  /* in k, R; par taylor_switch: Fourier top-hat W(kR)    cosmology.py:30-38 */
 #define HMG_FN_LINCOMB3      24  /* in X0, X1, X2; par a, b, c -> a X0 + b X1 + c X2
                                     (total_matter_power_spectrum etc.)                 cosmology.py:599-658 */
-#define HMG_FN_BRUTE_INTEGRAND 25 /* in k (rows), r (cols), rho (cols) -> 4 pi r sin(r k) rho / k
-                                    (uk_brute_force integrand)                         fft.py:22-33 */
-#define HMG_FN_COUNT         26
+#define HMG_FN_COUNT         25
 #define HMG_FN_MAXIN   6
 #define HMG_FN_MAXPAR 16
 int hmg_fn2d(hmg_ctx* ctx, int op, int rows, int cols, int nin, const double* const* h_d_in,
@@ -316,6 +345,13 @@ int hmg_comm_allgather(hmg_ctx* ctx, const double* d_send, double* d_recv, size_
 /* n gathers of count_per_rank doubles each, fused into one RCCL group launch. */
 int hmg_comm_allgather_multi(hmg_ctx* ctx, int n, const double* const* h_d_send,
                              double* const* h_d_recv, size_t count_per_rank);
+/* The gather of one pass off the compute stream: record ready_slot on the current lane, make
+ * comm_lane wait for it, issue the grouped all-gather there and record done_slot.  A later
+ * hmg_event_wait(done_slot) on the compute lane orders the next overwrite of the send buffers.   */
+int hmg_comm_gather_async(hmg_ctx* ctx, int n, const double* const* h_d_send, double* const* h_d_recv,
+                          size_t count_per_rank, int ready_slot, int done_slot, int comm_lane);
+/* rank and size as RCCL reports them (ncclCommUserRank / ncclCommCount); 0 and 1 without a communicator */
+int hmg_comm_info(hmg_ctx* ctx, int* h_rank, int* h_nranks);
 int hmg_comm_barrier(hmg_ctx* ctx);     /* blocks */
 int hmg_comm_destroy(hmg_ctx* ctx);
 

@@ -128,3 +128,32 @@ def test_medium_accuracy_through_provider_seam():
     assert rel_err(cos._get_matter_power(zs, ks), want) < 1e-14
     with pytest.raises(NotImplementedError):
         Cosmology(accuracy="low", engine="analytic").get_pk_interpolator(zs, 10.0)
+
+
+def test_bench_launcher_dry_run_and_failure_propagation():
+    """`python bench.py --gpus N` without a rank environment spawns the N ranks itself (the way the
+    driver starts N=1).  --dry-run shows the dispatch; on this GPU-less box the ranks fail at context
+    creation and the launcher must report that with a non-zero exit instead of hanging."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    bench = os.path.join(REPO, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_ranks"] == 2 and "--dry-run" not in d["cmd"] and d["cmd"][-2:] == ["--steps", "3"]
+    assert [e["RANK"] for e in d["rank_env"]] == ["0", "1"] and all(e["WORLD_SIZE"] == "2" for e in d["rank_env"])
+    assert len({e["MASTER_PORT"] for e in d["rank_env"]}) == 1 and d["rank_env"][0]["MASTER_ADDR"] == "127.0.0.1"
+    try:
+        import ctypes
+        ctypes.CDLL("libamdhip64.so").hipGetDeviceCount
+        has_gpu = os.path.exists("/dev/kfd")
+    except OSError:
+        has_gpu = False
+    if not has_gpu:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "rank exit codes" in r.stderr

@@ -6,12 +6,12 @@ R=${1:-3}; shift || true
 for i in $(seq $R); do
   for v in base new; do
     if [ $v = base ]; then export HMG_LIB_PATH=$PWD/hmvec_amd/libhmgrid_base.so; else unset HMG_LIB_PATH; fi
-    python bench.py --no-cpu-baseline --detail --steps 30 "$@" > /tmp/ab_$v.json
+    python bench.py --no-cpu-baseline --no-limber --steps 40 "$@" > /tmp/ab_$v.json
     python - $v <<'PY'
 import json, sys
 d = json.loads(open(f"/tmp/ab_{sys.argv[1]}.json").read().strip().splitlines()[-1])
 k = d["kernels"]
-print(f"{sys.argv[1]:5s} step {d['ms_per_step']:.4f}  power {d['roofline']['ms_per_launch']:.4f}  nfw {k['nfw_kernel']['ms']:.4f}  fused {k['profile_fused_kernel']['ms']:.4f}")
+print(f"{sys.argv[1]:5s} step {d['ms_per_step']:.4f}  power {k['power_batch_kernel']['ms']:.4f}  nfw {k['nfw_kernel']['ms']:.4f}  fused {k['profile_fused_kernel']['ms']:.4f}  host_issue {d['host_issue_ms_per_step']:.4f}")
 PY
   done
 done

@@ -10,11 +10,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof; mkdir -p $OUT
 python3 bench.py > $OUT/config3_bench.json
 echo "bench done"
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber > $OUT/kt.log 2>&1
 cp $OUT/kt/k_kernel_stats.csv $OUT/config3_kernel_stats.csv
 echo "kernel trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph > $OUT/pmc_$c.log 2>&1
 done
 cp $OUT/pmc_FETCH_SIZE/p_counter_collection.csv $OUT/pmc_fetch_counter_collection.csv
 cp $OUT/pmc_WRITE_SIZE/p_counter_collection.csv $OUT/pmc_write_counter_collection.csv
@@ -30,14 +30,20 @@ def per_kernel(path, counter):
         name = re.sub(r"\(.*", "", r["Kernel_Name"])
         tot[name] += float(r["Counter_Value"]); n[name] += 1
     return {k: tot[k] / n[k] for k in tot}
+cnt = defaultdict(int)
+for r in csv.DictReader(open(f"{out}/pmc_fetch_counter_collection.csv")):
+    if r["Counter_Name"] == "FETCH_SIZE":
+        cnt[re.sub(r"\(.*", "", r["Kernel_Name"])] += 1
+steps = max([v for k, v in cnt.items() if "power_batch_kernel" in k] + [1])     # one mass-integral launch per step
 f = per_kernel(f"{out}/pmc_fetch_counter_collection.csv", "FETCH_SIZE")
 w = per_kernel(f"{out}/pmc_write_counter_collection.csv", "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
-                 "--no-cpu-baseline; Config 3, 1 GPU (tools/profile_round.sh)",
+                 "--no-cpu-baseline --no-limber --no-graph; Config 3, 1 GPU (tools/profile_round.sh)",
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
                      "MI355X_MICROARCH.md, HBM section)",
        "kernels": {k: {"FETCH_SIZE_KB_per_launch": f.get(k, 0.0), "WRITE_SIZE_KB_per_launch": w.get(k, 0.0),
-                       "hbm_bytes_per_launch_corrected": (2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024} for k in sorted(set(f) | set(w))}}
+                       "hbm_bytes_per_launch_corrected": (2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024,
+                       "launches_per_step": round(cnt.get(k, 0) / max(steps, 1), 3)} for k in sorted(set(f) | set(w))}}
 json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 for k, v in res["kernels"].items():
     print(f"{v['hbm_bytes_per_launch_corrected']/1e6:10.1f} MB  {k}")

@@ -3,10 +3,12 @@
 # 1/2/4/8-GPU job computes).  Usage: tools/slab_sweep.sh [extra bench.py flags]; env passes through.
 set -e
 for nz in ${SLABS:-32 16 8 4}; do
-  python bench.py --nz $nz --no-cpu-baseline --steps 50 "$@" > /tmp/slab_$nz.json
+  python bench.py --nz $nz --no-cpu-baseline --no-limber --steps 50 "$@" > /tmp/slab_$nz.json
   python - $nz <<'PY'
 import json, sys
 d = json.loads(open(f"/tmp/slab_{sys.argv[1]}.json").read().strip().splitlines()[-1])
-print(f"nz={sys.argv[1]:>3}  ms_per_step={d['ms_per_step']:.4f}  host_issue_ms={d['host_issue_ms_per_step']:.4f}  power_kernel_ms={d['roofline']['ms_per_launch']:.4f}")
+k = d["kernels"]
+print(f"nz={sys.argv[1]:>3}  ms_per_step={d['ms_per_step']:.4f}  host_issue_ms={d['host_issue_ms_per_step']:.4f}  "
+      f"power={k['power_batch_kernel']['ms']:.4f} nfw={k['nfw_kernel']['ms']:.4f} fused={k['profile_fused_kernel']['ms']:.4f}  [{d['launch_mode']}]")
 PY
 done
