@@ -335,8 +335,14 @@ def main():
 
     kern_ms = {k: [] for k in BR}
     stage_ms = []
+    t_wait = [0.0]        # host time spent waiting for bracket events (not launch work)
 
     def read_brackets():
+        t_in = time.perf_counter()
+        _read_brackets()
+        t_wait[0] += time.perf_counter() - t_in
+
+    def _read_brackets():
         for k in BR:
             if not (k == "power" and args.per_pair):
                 kern_ms[k].append(ctx.elapsed_ms(*EV_BR[k]))
@@ -368,7 +374,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(K):
         step(s)
-    t_issue = time.perf_counter() - t0        # host time to enqueue K steps (launches are asynchronous)
+    t_issue = time.perf_counter() - t0 - t_wait[0]   # host time to enqueue K steps (launches are asynchronous)
     comm.barrier()
     ctx.sync()
     dt = time.perf_counter() - t0

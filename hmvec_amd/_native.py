@@ -74,10 +74,14 @@ SIGNATURES = {
     "hmg_elapsed_ms": [_P, _I, _I, C.POINTER(_D)],
     "hmg_bracket_next": [_P, _I, _I, _I],
     "hmg_sigma2": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P],
+    "hmg_sigma2_layout_size": [_I, _I, C.POINTER(_Z)],
+    "hmg_sigma2_prepare": [_P, _I, _I, _P, _P],
+    "hmg_sigma2_prepared": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P],
+    "hmg_halo_stage": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P, _P, _P, _D, _P, _P, _P],
     "hmg_massfn": [_P, _I, _I, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P],
     "hmg_halo_structure": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P],
     "hmg_mdelta_convert": [_P, _I, _I, _P, _P, _P, _D, _P, _P, _P],
-    "hmg_nfw_analytic": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hmg_nfw_analytic": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hmg_profile_rowparams": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, C.POINTER(_D * 9), _D, _D, _D,
                               _D, _P, _P, _P, _P, _P, _P, _P],
     "hmg_profile_rows_from_mvir": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _D, _P, _P, C.POINTER(_D * 9), _D, _D,
@@ -214,6 +218,7 @@ class Context:
         check(self.lib.hmg_ctx_create(int(device), C.byref(h)))
         self.handle = h.value
         self.device = int(device)
+        self.capture_serial = 0       # changes at every capture begin/end: events recorded before are off limits
 
     def close(self):
         if getattr(self, "handle", None):
@@ -272,13 +277,18 @@ class Context:
         """Run ``fn()`` (launch-only: no allocation, upload, download or synchronisation) inside a
         HIP-graph capture and return the graph id for ``replay``."""
         check(self.lib.hmg_graph_begin(self.handle))
+        self.capture_serial += 1
         try:
             fn()
         except BaseException:
             self.lib.hmg_graph_abort(self.handle)
+            self.capture_serial += 1
             raise
         gid = C.c_int()
-        check(self.lib.hmg_graph_end(self.handle, C.byref(gid)))
+        try:
+            check(self.lib.hmg_graph_end(self.handle, C.byref(gid)))
+        finally:
+            self.capture_serial += 1
         return gid.value
 
     def replay(self, gid):

@@ -34,10 +34,15 @@ static int fail(const char* what, const char* detail, const char* file, int line
     g_last_error = buf;
     return 1;
 }
+// (a failed runtime call also leaves a sticky "last error" behind: clear it, or the next
+// hipGetLastError() check after a perfectly good kernel launch would report it again)
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
         hipError_t e_ = (expr);                                                         \
-        if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (e_ != hipSuccess) {                                                         \
+            (void)hipGetLastError();                                                    \
+            return fail(#expr, hipGetErrorString(e_), __FILE__, __LINE__);              \
+        }                                                                               \
     } while (0)
 #define FFT_TRY(expr)                                                                   \
     do {                                                                                \
@@ -83,8 +88,8 @@ struct hmg_ctx {
     hipEvent_t ev[HMG_EVENT_SLOTS] = {};
     int bracket[HMG_KERNEL_COUNT][2];  // one-shot event brackets per kernel id, -1 = off
     // grow-only scratch arenas (device)
-    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void* scratch[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
     std::map<std::pair<int, int>, FftPlan> plans;  // (nxs, batch) -> plan
     std::map<int, struct FusedPlan> fused;          // nxs -> workgroup-FFT tables
     size_t fft_chunk_bytes = 0;                    // 0 = default
@@ -458,14 +463,11 @@ constexpr double NFW_X2 = 10.0;
 // With 32 terms the series stays within 3e-15 (absolute, against 50-digit arithmetic, c in [0.5, 100])
 // up to (1+c) x = 10: the band 4 < (1+c) x <= 10 - where x itself is still on the small-argument
 // branch of Si/Ci, the most expensive case of the closed form - costs 32 FMAs instead.
-__global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, double* __restrict__ acoef) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
+__device__ __forceinline__ void nfw_series_row(double c, double* __restrict__ a) {
     constexpr double INVFACT[NFW_NS2] = {1.0, 0.16666666666666666, 0.008333333333333333, 0.0001984126984126984, 2.7557319223985893e-06, 2.505210838544172e-08, 1.6059043836821613e-10, 7.647163731819816e-13, 2.8114572543455206e-15, 8.22063524662433e-18, 1.9572941063391263e-20, 3.8681701706306835e-23, 6.446950284384474e-26, 9.183689863795546e-29, 1.1309962886447718e-31, 1.2161250415535181e-34, 1.151633562077195e-37, 9.67759295863189e-41, 7.265460179153071e-44, 4.902469756513544e-47, 2.9893108271424046e-50, 1.6552108677421951e-53, 8.359650847182804e-57, 3.866628513960594e-60, 1.643974708316579e-63, 6.446959640457174e-67, 2.3392451525606576e-70, 7.876246304918039e-74, 2.4674957095607893e-77, 7.210682961895936e-81, 1.9701319568021682e-84, 5.043860616493007e-88};
-    const double c = cs[row], opc = 1.0 + c;
+    const double opc = 1.0 + c;
     const double mc = log(opc) - c / opc;
     const double inv_mc = 1.0 / mc;
-    double* a = acoef + (size_t)row * NFW_NS2;
     double jm2 = c / opc, jm1 = mc, cp = c;   // J_0, J_1, c^(p-1) for p = 2
     a[0] = (c >= 0.5) ? 1.0 : 0.0;
     for (int p = 2; p < 2 * NFW_NS2; ++p) {
@@ -478,6 +480,11 @@ __global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, doubl
         jm2 = jm1;
         jm1 = jp;
     }
+}
+__global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, double* __restrict__ acoef) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    nfw_series_row(cs[row], acoef + (size_t)row * NFW_NS2);
 }
 
 // ktile = k values per workgroup (a multiple of the block size)
@@ -630,6 +637,33 @@ __global__ void rows_from_mvir_kernel(int kind, int nz, int nm, const double* __
     r2[idx] = R2;
     rowparams_body(kind, idx, M2, R2, rvir[idx], 1.0 + zs[z], rhoc[z], hz ? hz[z] : 1.0, F, gamma,
                    alpha_const, pref, post_pref, O);
+}
+
+// c, rvir, rs + the NFW series row + the mass conversion of one (z,m) per thread: the three
+// per-(z,m) launches that precede the profile kernels of a pass, in one (hmg_halo_stage).
+__device__ __forceinline__ void nfw_series_row(double c, double* __restrict__ a);
+__global__ void halo_stage_kernel(int nz, int nm, const double* __restrict__ ms, const double* __restrict__ zs,
+                                  const double* __restrict__ delta, const double* __restrict__ rho, double A,
+                                  double alpha, double beta, double h, double* __restrict__ cs,
+                                  double* __restrict__ rv, double* __restrict__ rs,
+                                  double* __restrict__ series /*[nz*nm][NFW_NS2] or null*/,
+                                  const double* __restrict__ d1, double delta2, const double* __restrict__ rho2,
+                                  double* __restrict__ m2, double* __restrict__ r2 /* both or neither */) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nz * nm) return;
+    const int z = idx / nm, m = idx - z * nm;
+    const double mm = ms[m];
+    const double c = A * pow(h * mm / 2.0e12, alpha) * pow(1.0 + zs[z], beta);
+    const double r = pow(3.0 * mm / 4.0 / M_PI / delta[z] / rho[z], 1.0 / 3.0);
+    cs[idx] = c;
+    rv[idx] = r;
+    rs[idx] = r / c;
+    if (m2) {
+        const double M2 = mdelta_solve(mm, c, d1[z] / (delta2 * rho2[z]));
+        m2[idx] = M2;
+        r2[idx] = cbrt(3.0 * M2 / 4.0 / M_PI / delta2 / rho2[z]);
+    }
+    if (series) nfw_series_row(c, series + (size_t)idx * NFW_NS2);
 }
 
 // ---------------------------------------------------------------- K4: profile integrand (F1)
@@ -891,7 +925,14 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
         if (threadIdx.x == 0) s_mn = A.do_norm ? tot : 1.0;
     }
     __syncthreads();
+#if defined(HMG_ABL) && HMG_ABL == 1     // timing experiments only: stop after phase A
+    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + s_mn;
+    return;
+#endif
     // ---- phase B: in-place Stockham FFT of length M
+    // (Tried and dropped, MI355X: fetching all R operands before the twiddle products and requesting the
+    // next pass's twiddle between the two halves of a pass.  Both lengthen live ranges under the 64-VGPR
+    // cap of 8 waves/SIMD: 0.277 -> 0.315 ms.)
     for (int ps = pruned ? 1 : 0; ps < A.plan.npass; ++ps) {
         const int R = A.plan.radix[ps], Ns = A.plan.ns[ps], tws = A.plan.twstep[ps];
         const unsigned mg = A.plan.magic[ps];
@@ -904,6 +945,10 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
         else if (R == 3) { if (one) fused_pass<NT, 3, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
         else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
     }
+#if defined(HMG_ABL) && HMG_ABL == 2     // stop after phase B
+    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + s_mn;
+    return;
+#endif
     // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm for the reachable modes
     // j = 1..jn, into smem[0..jn-1]
     const double inv_mn = 1.0 / s_mn;
@@ -936,6 +981,10 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     }
     if (threadIdx.x == 0) u[M - 1] = 0.0;  // Nyquist mode: Im F_M == 0
     __syncthreads();
+#if defined(HMG_ABL) && HMG_ABL == 3     // stop after phase C
+    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = u[threadIdx.x];
+    return;
+#endif
     // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid:
     // bracket j = floor(k/k_lo), weight k/k_lo - j (one FMA), two LDS reads.  The left fill is a
     // plain splat (63 % of the Battaglia tensor at Config 3).
@@ -2178,33 +2227,53 @@ static int bracket_close(hmg_ctx* c, int stop_slot) {
     return 0;
 }
 
-int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const double* kq,
-               const double* wq, const double* R, double tswitch, double* out) {
-    REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
-    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
-    const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
-    const int zb = nz > 16 ? 2 : 1;
-    const int ztile = 16 * zb;
-    const int nzp = (nz + ztile - 1) / ztile * ztile;
-    if (ensure_scratch(c, 4, (size_t)nseg * nz * nm * 8 + (size_t)nq * nzp * 8)) return 1;
-    double* partial = (double*)c->scratch[4];
-    double* PT = partial + (size_t)nseg * nz * nm;
+static inline int sigma2_ztile(int nz) { return nz > 16 ? 32 : 16; }
+static inline int sigma2_nzp(int nz) { const int t = sigma2_ztile(nz); return (nz + t - 1) / t * t; }
+
+int hmg_sigma2_layout_size(int nz, int nq, size_t* doubles) {
+    REQUIRE(doubles && nz > 0 && nq > 0, "bad argument");
+    *doubles = (size_t)nq * sigma2_nzp(nz);
+    return 0;
+}
+int hmg_sigma2_prepare(hmg_ctx* c, int nz, int nq, const double* sP, double* PT) {
+    REQUIRE(c && sP && PT, "NULL argument");
+    REQUIRE(nz > 0 && nq > 0, "empty grid");
+    const int nzp = sigma2_nzp(nz);
     hipLaunchKernelGGL(transpose_pad_kernel, grid1d((size_t)nzp * nq, 256), dim3(256), 0, c->stream, nz, nzp,
                        nq, sP, PT);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+int hmg_sigma2_prepared(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq,
+                        const double* wq, const double* R, double tswitch, double* out) {
+    REQUIRE(c && PT && kq && wq && R && out, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
+    const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
+    const int ztile = sigma2_ztile(nz), nzp = sigma2_nzp(nz);
+    if (ensure_scratch(c, 4, (size_t)nseg * nz * nm * 8)) return 1;
+    double* partial = (double*)c->scratch[4];
     dim3 grid((nm + 15) / 16, nseg, nzp / ztile);
     REQUIRE(grid.y <= 65535 && grid.z <= 65535, "grid too large");
-    if (zb == 2)
+    if (ztile == 32)
         hipLaunchKernelGGL(sigma2_mfma_kernel<2>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
-                           (const double*)PT, kq, wq, R, tswitch, partial);
+                           PT, kq, wq, R, tswitch, partial);
     else
         hipLaunchKernelGGL(sigma2_mfma_kernel<1>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
-                           (const double*)PT, kq, wq, R, tswitch, partial);
+                           PT, kq, wq, R, tswitch, partial);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sigma2_combine_kernel, grid1d((size_t)nz * nm, 64), dim3(256), 0, c->stream,
                        nz * nm, nseg, (const double*)partial, out);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const double* kq,
+               const double* wq, const double* R, double tswitch, double* out) {
+    REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
+    if (ensure_scratch(c, 6, (size_t)nq * sigma2_nzp(nz) * 8)) return 1;
+    double* PT = (double*)c->scratch[6];
+    if (hmg_sigma2_prepare(c, nz, nq, sP, PT)) return 1;
+    return hmg_sigma2_prepared(c, nz, nm, nq, PT, kq, wq, R, tswitch, out);
 }
 
 int hmg_massfn(hmg_ctx* c, int nz, int nm, const hmg_massfn_params* p, const double* s2,
@@ -2231,6 +2300,20 @@ int hmg_halo_structure(hmg_ctx* c, int nz, int nm, const double* ms, const doubl
     return 0;
 }
 
+int hmg_halo_stage(hmg_ctx* c, int nz, int nm, const double* ms, const double* zs, const double* delta,
+                   const double* rho, double A, double alpha, double beta, double h, double* cs, double* rv,
+                   double* rs, double* nfw_series, const double* drho1, double delta2, const double* rho2,
+                   double* m2, double* r2) {
+    REQUIRE(c && ms && zs && delta && rho && cs && rv && rs, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    REQUIRE((m2 == nullptr) == (r2 == nullptr), "pass both d_m2 and d_r2 or neither");
+    REQUIRE(!m2 || (drho1 && rho2), "the mass conversion needs d_drho1 and d_rho2");
+    hipLaunchKernelGGL(halo_stage_kernel, grid1d((size_t)nz * nm, 64), dim3(64), 0, c->stream, nz, nm, ms, zs,
+                       delta, rho, A, alpha, beta, h, cs, rv, rs, nfw_series, drho1, delta2, rho2, m2, r2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int hmg_mdelta_convert(hmg_ctx* c, int nz, int nm, const double* ms, const double* cs,
                        const double* d1, double delta2, const double* rho2, double* m2, double* r2) {
     REQUIRE(c && ms && cs && d1 && rho2 && m2 && r2, "NULL argument");
@@ -2242,7 +2325,7 @@ int hmg_mdelta_convert(hmg_ctx* c, int nz, int nm, const double* ms, const doubl
 }
 
 int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const double* rs,
-                     const double* zs, const double* ks, double* uk) {
+                     const double* zs, const double* ks, const double* series, double* uk) {
     REQUIRE(c && cs && rs && zs && ks && uk, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
     // 16 k per thread amortise the per-row prologue (a log, two divisions, the scalar loads of the
@@ -2255,14 +2338,18 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
     REQUIRE(ktile >= threads && ktile % threads == 0, "HMG_NFW_KTILE must be a multiple of the block size");
     const size_t blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
     REQUIRE(blocks <= 2147483647u, "grid too large");
-    if (ensure_scratch(c, 5, (size_t)nz * nm * NFW_NS2 * 8)) return 1;
-    double* acoef = (double*)c->scratch[5];
-    hipLaunchKernelGGL(nfw_series_kernel, grid1d((size_t)nz * nm, 128), dim3(128), 0, c->stream, nz * nm, cs, acoef);
-    HIP_TRY(hipGetLastError());
+    const double* acoef = series;
+    if (!acoef) {      // the caller did not bring the series rows (hmg_halo_stage): build them here
+        if (ensure_scratch(c, 5, (size_t)nz * nm * NFW_NS2 * 8)) return 1;
+        acoef = (const double*)c->scratch[5];
+        hipLaunchKernelGGL(nfw_series_kernel, grid1d((size_t)nz * nm, 128), dim3(128), 0, c->stream, nz * nm, cs,
+                           (double*)c->scratch[5]);
+        HIP_TRY(hipGetLastError());
+    }
     int stop = -1;
     if (bracket_open(c, HMG_KERNEL_NFW, &stop)) return 1;
     hipLaunchKernelGGL(nfw_kernel, dim3((unsigned)blocks), dim3(threads), 0, c->stream, c->d_sici,
-                       (const double*)acoef, ktile, nm, nk, cs, rs, zs, ks, uk);
+                       acoef, ktile, nm, nk, cs, rs, zs, ks, uk);
     HIP_TRY(hipGetLastError());
     if (bracket_close(c, stop)) return 1;
     return 0;

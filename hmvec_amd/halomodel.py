@@ -143,8 +143,7 @@ class HaloModel(Cosmology):
         self.hods = {}
         self._dcache = {}
         self._pool = {}
-        self._use_lanes = os.environ.get("HMG_LANES", "0") == "1"   # multi-stream overlap; off by default
-        self._recorded = set()
+        self._use_lanes = os.environ.get("HMG_LANES", "0") == "1"   # two-stream overlap
 
         # (name, name2) -> (state version, P1h, P2h): a fused launch yields both terms, so the
         # usual get_power_1halo(a,b) followed by get_power_2halo(a,b) streams the tensors once
@@ -205,28 +204,49 @@ class HaloModel(Cosmology):
             self._dcache[key] = self._ctx().upload(builder())
         return self._dcache[key]
 
-    # -- lanes (multi-stream dataflow).  Lane 0: sigma2 -> n(z,m), b(z,m) -> HOD -> spectra.
-    # Lane 1: c, rvir, r_s -> analytic NFW.  Lane 2: mass conversion -> profile rows -> FFT.
-    # Event slots 0..7 are reserved for this class (bench.py uses slots >= 16).
-    _EV_EPOCH, _EV_HALO, _EV_TAIL1, _EV_TAIL2 = 0, 1, 2, 3
+    # -- lanes (two-stream dataflow, HMG_LANES=1).  The main lane (0) carries the chip-filling kernels
+    # in sequence - c, rvir -> NFW -> mass conversion + rows -> FFT -> spectra - and the auxiliary lane
+    # (1) the short latency-bound chain sigma2 -> n(z,m), b(z,m) -> HOD, which only needs a few CUs
+    # for a few microseconds at a time and so hides inside the big kernels' ramps and tails.  Ordering:
+    # an auxiliary launch waits for the last SYNC POINT of the main lane (start of a pass / end of the
+    # last spectra launch: whatever still reads n, b or the HOD arrays was enqueued before it), the
+    # spectra wait for the auxiliary lane.  All events used inside a capture are recorded inside it.
+    # Event slots 0..3 are reserved for this class (ShardedSpectra: 8-9, bench.py: 40 and up).
+    _AUX = 1
+    _EV_SYNC, _EV_AUX = 0, 1
 
-    def _on_lane(self, lane, wait_slots=()):
-        ctx = self._ctx()
-        ctx.lane(lane if self._use_lanes else 0)
+    def _sync_point(self):
         if self._use_lanes:
-            for sl in wait_slots:
-                if sl in self._recorded:
-                    ctx.wait(sl)
+            ctx = self._ctx()
+            ctx.lane(0)
+            ctx.record(self._EV_SYNC)
+            self._sync_serial = ctx.capture_serial
+
+    def _aux(self):
+        """Route the next launches to the auxiliary lane (no-op without lanes)."""
+        ctx = self._ctx()
+        if self._use_lanes:
+            if getattr(self, "_sync_serial", None) != ctx.capture_serial:
+                self._sync_point()          # first auxiliary launch of this capture / eager epoch
+            ctx.lane(self._AUX)
+            ctx.wait(self._EV_SYNC)
         return ctx
 
-    def _mark(self, slot):
+    def _aux_done(self):
         if self._use_lanes:
-            self._ctx().record(slot)
-            self._recorded.add(slot)
+            ctx = self._ctx()
+            ctx.record(self._EV_AUX)
+            self._aux_pending = True
+            ctx.lane(0)
 
-    def _join_profiles(self):
-        """Lane 0 waits for everything enqueued on the profile lanes."""
-        return self._on_lane(0, (self._EV_TAIL1, self._EV_TAIL2))
+    def _main(self, needs_aux=False):
+        """Main lane; with needs_aux the launches that follow also wait for the auxiliary lane."""
+        ctx = self._ctx()
+        if self._use_lanes:
+            ctx.lane(0)
+            if needs_aux and getattr(self, "_aux_pending", False):
+                ctx.wait(self._EV_AUX)
+        return ctx
 
     def _buf(self, key, shape):
         """Output/workspace buffer allocated once per key, so that re-running a stage is
@@ -324,12 +344,18 @@ class HaloModel(Cosmology):
             else:
                 self.sPzk = self.P_lin_approx(kq, self.zs)
             wq = simpson_weights(kq) * kq ** 2.0 / 2.0 / np.pi ** 2
-            self._dcache["sig_in"] = tuple(ctx.upload(a) for a in (self.sPzk, kq, wq, self.R_of_m(ms)))
-        d_sP, d_kq, d_wq, d_R = self._dcache["sig_in"]
-        ctx = self._join_profiles()      # everything launched so far is ordered before this point
-        self._mark(self._EV_EPOCH)
+            d_sP = ctx.upload(self.sPzk)
+            # P(k',z) is an input of the path: lay it out once as the contraction reads it
+            n = C.c_size_t()
+            nat.check(ctx.lib.hmg_sigma2_layout_size(nz, kq.size, C.byref(n)))
+            d_PT = ctx.empty((n.value,))
+            ctx.call("hmg_sigma2_prepare", nz, kq.size, d_sP.ptr, d_PT.ptr)
+            self._dcache["sig_in"] = (d_PT,) + tuple(ctx.upload(a) for a in (kq, wq, self.R_of_m(ms)))
+        d_PT, d_kq, d_wq, d_R = self._dcache["sig_in"]
+        self._sync_point()               # start of a pass: everything launched so far precedes it
+        ctx = self._aux()
         self._d_sigma2 = self._buf("sigma2", (nz, nm))
-        ctx.call("hmg_sigma2", nz, nm, d_kq.size, d_sP.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
+        ctx.call("hmg_sigma2_prepared", nz, nm, d_kq.size, d_PT.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
                  float(self.p["Wkr_taylor_switch"]), self._d_sigma2.ptr)
         # n(z,m), b(z,m)
         if "mf_in" not in self._dcache:
@@ -346,18 +372,23 @@ class HaloModel(Cosmology):
         self._d_nzm, self._d_bh = self._buf("nzm", (nz, nm)), self._buf("bh", (nz, nm))
         ctx.call("hmg_massfn", nz, nm, C.byref(par), self._d_sigma2.ptr, self._d_ms().ptr, d_lnm.ptr,
                  nat.ptr(d_tz), self._d_nzm.ptr, self._d_bh.ptr)
-        # c(z,m), rvir(z,m), rs(z,m): independent of sigma2 -> lane 1
+        self._aux_done()
+        # c(z,m), rvir(z,m), rs(z,m): independent of sigma2 -> main lane, ahead of the profile kernels
         sfx = self.mdef
         self._d_cs, self._d_rvir, self._d_rs = (self._buf(k, (nz, nm)) for k in ("cs", "rvir", "rs"))
-        ctx = self._on_lane(1, (self._EV_EPOCH,))
-        ctx.call("hmg_halo_structure", nz, nm, self._d_ms().ptr, self._d_zs().ptr, d_delta.ptr, d_rho.ptr,
+        # ... together with the series rows of the analytic NFW kernel and the vir -> 200c mass
+        # conversion the Battaglia profiles need (all one thread per (z,m): one launch)
+        self._d_nfw_series = self._buf("nfw_series", (nz, nm, 32))
+        m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
+        d_drho1 = self._d_drho1()
+        d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
+        ctx = self._main()
+        ctx.call("hmg_halo_stage", nz, nm, self._d_ms().ptr, self._d_zs().ptr, d_delta.ptr, d_rho.ptr,
                  float(self.p["duffy_A_" + sfx]), float(self.p["duffy_alpha_" + sfx]),
                  float(self.p["duffy_beta_" + sfx]), float(self.h),
-                 self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr)
-        self._mark(self._EV_HALO)
-        self._mark(self._EV_TAIL1)
-        self._on_lane(0)
-        self._m200c_valid = False
+                 self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr, self._d_nfw_series.ptr,
+                 d_drho1.ptr, 200.0, d_rhoc.ptr, m2.ptr, r2.ptr)
+        self._m200c_valid = True
 
     def get_fsigmaz(self):
         """Multiplicity function f(sigma, z) on the (z,m) grid (hmvec/hmvec.py:133-147).  The path
@@ -392,8 +423,6 @@ class HaloModel(Cosmology):
         nz, nm = self._nz, self._nm
         m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
         if not getattr(self, "_m200c_valid", False):
-            if self._use_lanes and self._EV_HALO in self._recorded:
-                ctx.wait(self._EV_HALO)       # c(z,m) is produced on lane 1
             d1 = self._d_drho1()
             d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
             ctx.call("hmg_mdelta_convert", nz, nm, self._d_ms().ptr, self._d_cs.ptr, d1.ptr, 200.0,
@@ -452,8 +481,6 @@ class HaloModel(Cosmology):
         d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
         if not getattr(self, "_m200c_valid", False):
             # mass conversion and row parameters in one launch
-            if self._use_lanes and self._EV_HALO in self._recorded:
-                ctx.wait(self._EV_HALO)
             m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
             ctx.call("hmg_profile_rows_from_mvir", kind, nz, nm, self._d_ms().ptr, self._d_cs.ptr,
                      self._d_rvir.ptr, self._d_zs().ptr, self._d_drho1().ptr, 200.0, d_rhoc.ptr, d_hz.ptr,
@@ -490,13 +517,11 @@ class HaloModel(Cosmology):
         gamma = pparams["battaglia_gas_gamma"]
         fit9 = [pparams[a + b] for a in ("rho0_", "alpha_", "beta_") for b in ("A0", "alpham", "alphaz")]
         key = ("uk", name)
-        self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
+        self._main()
         amp, xc, alpha, expo, cmax, rscale, _post = self._battaglia_rowparams(
             key, nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0)
         out, hint = self._profile_fft(key, nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
                                       cmax, rscale, True)
-        self._mark(self._EV_TAIL2)
-        self._on_lane(0)
         self.uk_profiles.set_dev(name, out, hint)
 
     def add_battaglia_pres_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
@@ -529,13 +554,11 @@ class HaloModel(Cosmology):
         mElect = constants.physical_constants["electron mass"][0] / default_params["mSun"]
         post_pref = 4 * np.pi * (sigmaT / (mElect * constants.c ** 2))
         key = ("pk", name)
-        self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
+        self._main()
         amp, xc, _alpha, expo, cmax, rscale, post = self._battaglia_rowparams(
             key, nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref)
         out, hint = self._profile_fft(key, nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
                                       cmax, rscale, False, d_post=post)
-        self._mark(self._EV_TAIL2)
-        self._on_lane(0)
         self.pk_profiles.set_dev(name, out, hint)
 
     def add_nfw_profile(self, name, numeric=False, nxs=None, xmax=None, ignore_existing=False):
@@ -550,19 +573,15 @@ class HaloModel(Cosmology):
         ctx = self._ctx()
         nz, nm, nk = self._nz, self._nm, self._nk
         hint = None
+        ctx = self._main()
         if numeric:
             # rho = 1/x/(1+x)^2 is the gamma=-1, alpha=1, expo=2 member of the family
-            self._on_lane(2, (self._EV_EPOCH, self._EV_HALO))
             out, hint = self._profile_fft(("uk", name), nxs, xmax, (None, None, None, None), (1.0, 1.0, 1.0, 2.0),
                                           -1.0, self._d_cs, self._d_rs, True)
-            self._mark(self._EV_TAIL2)
         else:
             out = self._buf(("uk", name), (nz, nm, nk))
-            ctx = self._on_lane(1, (self._EV_EPOCH,))
             ctx.call("hmg_nfw_analytic", nz, nm, nk, self._d_cs.ptr, self._d_rs.ptr, self._d_zs().ptr,
-                     self._d_ks().ptr, out.ptr)
-            self._mark(self._EV_TAIL1)
-        self._on_lane(0)
+                     self._d_ks().ptr, self._d_nfw_series.ptr, out.ptr)
         self.uk_profiles.set_dev(name, out, hint)
         return self.ks, _LazyArray(self.uk_profiles, name)
 
@@ -587,9 +606,12 @@ class HaloModel(Cosmology):
         d_thr = cached[1]
         out = {k: self._buf((key, k), (nz, nm)) for k in ("Nc", "Ns", "NsNsm1", "NcNs")}
         out["ngal"], out["bg"] = self._buf((key, "ngal"), (nz,)), self._buf((key, "bg"), (nz,))
-        ctx.call("hmg_hod", nz, nm, C.byref(par), self._d_zs().ptr, self._d_ms().ptr, d_thr.ptr,
-                 self._d_nzm.ptr, self._d_bh.ptr, self._d_wm().ptr, out["Nc"].ptr, out["Ns"].ptr,
+        d_wm, d_ms, d_zs = self._d_wm(), self._d_ms(), self._d_zs()     # (uploads, if any, before the lane switch)
+        ctx = self._aux()
+        ctx.call("hmg_hod", nz, nm, C.byref(par), d_zs.ptr, d_ms.ptr, d_thr.ptr,
+                 self._d_nzm.ptr, self._d_bh.ptr, d_wm.ptr, out["Nc"].ptr, out["Ns"].ptr,
                  out["NsNsm1"].ptr, out["NcNs"].ptr, out["ngal"].ptr, out["bg"].ptr)
+        self._aux_done()
         return out
 
     def add_hod(self, name, mthresh=None, ngal=None, corr="max", satellite_profile_name="nfw",
@@ -683,13 +705,14 @@ class HaloModel(Cosmology):
         raise ValueError
 
     def _power_launch(self, ta, tb, want1, want2, out1=None, out2=None):
-        ctx = self._join_profiles()
+        ctx = self._main(needs_aux=True)
         nz, nm, nk = self._nz, self._nm, self._nk
         d1 = (out1 if out1 is not None else ctx.empty((nz, nk))) if want1 else None
         d2 = (out2 if out2 is not None else ctx.empty((nz, nk))) if want2 else None
         ctx.call("hmg_power", nz, nm, nk, C.byref(ta), C.byref(tb), self._d_nzm.ptr, self._d_bh.ptr,
                  self._d_ms().ptr, self._d_wm().ptr, self._d_ks().ptr, self._d_Pzk().ptr,
                  self._rho_m0(), float(self.p["kstar_damping"]), nat.ptr(d1), nat.ptr(d2))
+        self._sync_point()
         return d1, d2
 
     def _rho_m0(self):
@@ -760,7 +783,7 @@ class HaloModel(Cosmology):
             alias.append(uniq.index(key))
         first = [alias.index(u) for u in range(len(uniq))]
         n = len(uniq)
-        ctx = self._join_profiles()
+        ctx = self._main(needs_aux=True)
         tr = (nat.Tracer * len(names))(*[r[0] for r in res1])
         pa = (C.c_int * n)(*[u[0] for u in uniq])
         pb = (C.c_int * n)(*[u[1] for u in uniq])
@@ -769,6 +792,7 @@ class HaloModel(Cosmology):
         ctx.call("hmg_power_batch", nz, nm, nk, len(names), tr, n, pa, pb, self._d_nzm.ptr, self._d_bh.ptr,
                  self._d_ms().ptr, self._d_wm().ptr, self._d_ks().ptr, self._d_Pzk().ptr,
                  self._rho_m0(), float(self.p["kstar_damping"]), p1, p2)
+        self._sync_point()
         for i, u in enumerate(alias):
             if first[u] != i:
                 ctx.lib.hmg_memcpy_d2d(ctx.handle, o1[i].ptr, o1[first[u]].ptr, o1[i].nbytes)
@@ -893,7 +917,7 @@ class HaloModel(Cosmology):
         """(I_1, C_1, I_2, C_2) of the 2-halo term (hmvec/hmvec.py:563-568): the mass integrals
         I(z,k) = int dm n b W(k), shape (nz,nk), and their k -> 0 consistency limits C(z), shape (nz,1)."""
         name2 = name if name2 is None else name2
-        ctx = self._join_profiles()
+        ctx = self._main(needs_aux=True)
         nz, nm, nk = self._nz, self._nm, self._nk
         ta, tb = self._tracer(name, "mph")[0], self._tracer(name2, "mph")[0]
         d_i1, d_i2, d_c = ctx.empty((nz, nk)), ctx.empty((nz, nk)), ctx.empty((nz, 2))

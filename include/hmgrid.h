@@ -95,6 +95,15 @@ int hmg_sigma2(hmg_ctx* ctx, int nz, int nm, int nq,
                const double* d_sPzk /*[nz][nq]*/, const double* d_kq /*[nq]*/,
                const double* d_wq /*[nq]*/, const double* d_R /*[nm]*/,
                double taylor_switch, double* d_sigma2 /*[nz][nm]*/);
+/* The contraction reads P from a [k'][z] transposed, zero-padded copy (the MFMA A operand).  A caller
+ * whose sPzk does not change between passes (the usual case: it is an INPUT of the path) lays it out
+ * once - hmg_sigma2_layout_size doubles, hmg_sigma2_prepare - and calls hmg_sigma2_prepared, which
+ * is hmg_sigma2 minus the transposition launch.  Same arithmetic, same result, bit for bit.        */
+int hmg_sigma2_layout_size(int nz, int nq, size_t* h_doubles);
+int hmg_sigma2_prepare(hmg_ctx* ctx, int nz, int nq, const double* d_sPzk, double* d_PT);
+int hmg_sigma2_prepared(hmg_ctx* ctx, int nz, int nm, int nq, const double* d_PT,
+                        const double* d_kq, const double* d_wq, const double* d_R,
+                        double taylor_switch, double* d_sigma2);
 
 /* ---- A3/A4: mass function n(z,m) and halo bias b(z,m) -----------------------------
  * Replaces get_fsigmaz/get_bh/get_nzm (hmvec/hmvec.py:133-161,178-185) and
@@ -124,6 +133,18 @@ int hmg_halo_structure(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const d
                        double* d_cs /*[nz][nm]*/, double* d_rvir /*[nz][nm]*/,
                        double* d_rs /*[nz][nm]*/);
 
+/* hmg_halo_structure, the series rows of the analytic NFW kernel and hmg_mdelta_convert in ONE launch
+ * (they are all one-thread-per-(z,m) stages that precede the profile kernels of a pass):
+ *   d_nfw_series [nz][nm][32] (or NULL): per-row coefficients of u_NFW's small-argument series, to be
+ *     handed to hmg_nfw_analytic, which otherwise computes them with a launch of its own;
+ *   d_m2, d_r2 (both or NULL): the mass conversion of hmg_mdelta_convert with d_drho1, delta2, d_rho2.  */
+int hmg_halo_stage(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const double* d_zs,
+                   const double* d_delta /*[nz]*/, const double* d_rho /*[nz]*/,
+                   double duffy_A, double duffy_alpha, double duffy_beta, double h,
+                   double* d_cs, double* d_rvir, double* d_rs, double* d_nfw_series,
+                   const double* d_drho1 /*[nz]*/, double delta2, const double* d_rho2 /*[nz]*/,
+                   double* d_m2, double* d_r2);
+
 /* ---- A7: mass-definition conversion -------------------------------------------------
  * Replaces mdelta_from_mdelta (hmvec/hmvec.py:748-798): the root in ln M2 of
  *   M1 F(c1) = M2 F(c2),  c2 = c1 ((M2/M1)(drho1/drho2))^(1/3),  F = 1/(ln(1+c)-c/(1+c)),
@@ -138,6 +159,7 @@ int hmg_mdelta_convert(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const d
  * Cephes sici (scipy.special.sici).                                                     */
 int hmg_nfw_analytic(hmg_ctx* ctx, int nz, int nm, int nk, const double* d_cs,
                      const double* d_rs, const double* d_zs, const double* d_ks,
+                     const double* d_nfw_series /* from hmg_halo_stage for the SAME d_cs, or NULL */,
                      double* d_uk /*[nz][nm][nk]*/);
 
 /* ---- A8/X1 row parameters of the generalised-NFW integrand ----------------------------

@@ -123,3 +123,77 @@ def test_ngal_mode_on_a_zslab_uses_the_global_bisection(capsys):
     slab = hm.HaloModel(zs[lo:hi], ks, ms=ms, **kw)
     slab.add_hod("g", mthresh=mthr[lo:hi])
     assert np.array_equal(slab.get_power("g"), full.get_power("g")[lo:hi])
+
+
+def test_config5_limber_at_full_size(full):
+    """BASELINE.json configs[4]: Config 3's grid + C_kk and C_kg at 2000 multipoles (lzs=2.5, gzs=0.8;
+    README.rst:106,123, hmvec/cosmology.py:536-568,867-904), from the device-resident GPU spectra
+    (P_1h + P_2h summed inside the Limber kernel) against the oracle's limber_integral on the same
+    (32 x 4096) arrays."""
+    from oracle import hmref
+    zs, ms, ks = grids()
+    ells = np.linspace(100, 6000, 2000)
+    lzs, gzs = 2.5, 0.8
+    ckk = full.C_kk(ells, zs, ks, full.power_device("nfw", "nfw"), lzs1=lzs, lzs2=lzs)
+    ckg = full.C_kg(ells, zs, ks, full.power_device("g", "nfw"), gzs=gzs, lzs=lzs)
+    Pmm, Pgm = full.get_power("nfw"), full.get_power("g", "nfw")
+    H0, chis, hz = full.h_of_z(0.0), full.comoving_radial_distance(zs), full.h_of_z(zs)
+    chistar = full.comoving_radial_distance(np.array([lzs]))
+    wz = hmref.lensing_window(zs, lzs, H0, hz, chis, chistar, full.omm0)
+    gz = np.array([gzs])
+    chig, hg = full.comoving_radial_distance(gz), full.h_of_z(gz)
+    wg = hmref.lensing_window(gz, lzs, H0, hg, chig, chistar, full.omm0)
+    okk = hmref.limber_integral(ells, zs, ks, Pmm, zs, wz, wz, hz, chis)
+    okg = hmref.limber_integral(ells, zs, ks, Pgm, gzs, wg, 1.0, hg, chig)
+    assert ckk.shape == ckg.shape == (2000,)
+    assert np.allclose(ckk, okk, rtol=1e-8, atol=0) and np.allclose(ckg, okg, rtol=1e-8, atol=0)
+    # the host-array route (what the reference's signature takes) gives the same numbers
+    assert np.allclose(full.C_kk(ells, zs, ks, Pmm, lzs1=lzs, lzs2=lzs), ckk, rtol=1e-13, atol=0)
+    assert np.all(ckk > 0) and np.all(np.diff(ckk) < 0)            # a lensing power spectrum: positive, falling
+
+
+def test_spectra_block_hand_over(full):
+    """All twelve (nz,nk) outputs through one device block and one pinned host block."""
+    blk = full.spectra_block(PAIRS)
+    blk.compute()
+    got = blk.fetch()
+    for a, b in PAIRS:
+        assert np.allclose(got[(a, b)][0], full.get_power_1halo(a, b), rtol=1e-12, atol=0), (a, b)
+        assert np.allclose(got[(a, b)][1], full.get_power_2halo(a, b), rtol=1e-12, atol=0), (a, b)
+
+
+def test_captured_step_replays_identically():
+    """A pass captured as a HIP graph reproduces the eager pass bit for bit, also after the inputs of
+    the pass changed in place (same buffers, new HOD thresholds)."""
+    import hmvec_amd as hm
+    zs = np.linspace(0.1, 2.5, 8)
+    ms = np.geomspace(2e10, 1e17, 128)
+    ks = np.geomspace(1e-4, 100, 512)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000)
+    thr = 10 ** 10.5 + zs * 0.0
+    h.add_hod("g", mthresh=thr)
+    blk = h.spectra_block(PAIRS)
+
+    def step():
+        h.init_mass_function(ms)
+        h.add_nfw_profile("nfw", ignore_existing=True)
+        h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000, ignore_existing=True)
+        h.add_hod("g", mthresh=thr, ignore_existing=True)
+        blk.compute()
+
+    step()
+    eager = {p: (a.copy(), b.copy()) for p, (a, b) in blk.fetch().items()}
+    ctx = h._ctx()
+    gid = ctx.capture(step)
+    for _ in range(3):
+        ctx.replay(gid)
+    replayed = blk.fetch()
+    for p in PAIRS:
+        assert np.array_equal(replayed[p][0], eager[p][0]) and np.array_equal(replayed[p][1], eager[p][1]), p
+    with pytest.raises(Exception):              # a step that would allocate cannot be captured
+        ctx.capture(lambda: h.add_battaglia_profile("other", family="SH", xmax=20, nxs=1000))
+    ctx.replay(gid)                             # ... and the failed capture leaves the context usable
+    again = blk.fetch()
+    assert np.array_equal(again[PAIRS[2]][1], eager[PAIRS[2]][1])
+    ctx.call("hmg_graph_destroy", gid)

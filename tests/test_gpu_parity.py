@@ -209,3 +209,56 @@ def test_limber_projections():
     h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
     ckk = h.C_kk(ells, zs, ks, h.get_power("nfw"), lzs1=lz, lzs2=lz)
     assert np.allclose(ckk, g["C_kk"], rtol=1e-8)
+
+
+def test_second_tracers_and_tsz_projections_vs_reference():
+    """case_d (reference outputs): the first-name-only rule for two different HOD names and two different
+    pressure names (hmvec/hmvec.py:510-513; order-dependent by tens of per cent), through both the
+    per-pair kernel and the cached/batched facade, and the tSZ projections C_yy / C_ky."""
+    g = load_golden("case_d")
+    h = build_gpu(g)
+    add_all(h, g)
+    zs, ks, meta = g["zs"], g["ks"], g["meta"]
+    h.add_hod("g2", mthresh=10 ** 11.0 + zs * 0.0, corr="min")
+    h.add_battaglia_pres_profile("y2", param_override=dict(P0_A0=25.0, xc_A0=0.6, battaglia_pres_gamma=-0.4),
+                                 nxs=meta["nxs"], xmax=meta["xmax"])
+    for a, b in (("g", "g2"), ("g2", "g"), ("y", "y2"), ("y2", "y")):
+        ok, w = power_close(h.get_power_1halo(a, b), g[f"P1h_{a}_{b}"])
+        assert ok, ("1h", a, b, w)
+        ok, w = power_close(h.get_power_2halo(a, b), g[f"P2h_{a}_{b}"])
+        assert ok, ("2h", a, b, w)
+        d1, d2 = h.power_device(a, b)
+        assert power_close(d1.numpy(), g[f"P1h_{a}_{b}"])[0] and power_close(d2.numpy(), g[f"P2h_{a}_{b}"])[0]
+    o1, o2 = h.power_device_batch([("g", "g2"), ("y2", "y"), ("g", "g")])      # not batchable: per-pair fallback
+    assert power_close(o1[0].numpy(), g["P1h_g_g2"])[0] and power_close(o1[1].numpy(), g["P1h_y2_y"])[0]
+    assert power_close(o2[2].numpy(), g["P2h_g_g"])[0]
+    ells, lz = g["ells"], meta["limber"]["lzs"]
+    Pyy = g["P1h_y_y"] + g["P2h_y_y"]
+    Pym = g["P1h_nfw_y"] + g["P2h_nfw_y"]
+    assert rel_err(h.C_yy(ells, zs, ks, Pyy), g["C_yy"]) < 1e-12
+    assert rel_err(h.C_ky(ells, zs, ks, Pym, lzs1=lz), g["C_ky"]) < 1e-12
+    # from the device-resident GPU spectra, (P_1h, P_2h) summed inside the Limber kernel
+    assert np.allclose(h.C_yy(ells, zs, ks, h.power_device("y", "y")), g["C_yy"], rtol=1e-8, atol=0)
+    assert np.allclose(h.C_ky(ells, zs, ks, h.power_device("nfw", "y"), lzs1=lz), g["C_ky"], rtol=1e-8, atol=0)
+
+
+def test_verbose_prints_the_two_consistency_integrals(capsys):
+    """get_power_2halo(verbose=True) prints both consistency limits and both integrals
+    (hmvec/hmvec.py:569-571); the numbers are the oracle's."""
+    from oracle import hmref
+    g = load_golden("case_a")
+    h = build_gpu(g)
+    add_all(h, g)
+    h.get_power_2halo("g", "electron", verbose=True)
+    out = capsys.readouterr().out
+    assert "Two-halo consistency1: " in out and "Two-halo consistency2: " in out
+    i1, c1, i2, c2 = h.two_halo_terms("g", "electron")
+    assert i1.shape == g["P2h_electron_g"].shape and c1.shape == (g["zs"].size, 1)
+    bg = np.asarray(h.hods["g"]["bg"])[:, None]
+    assert power_close(h.Pzk * (i1 + bg - c1) * (i2 + 1.0 - c2), g["P2h_electron_g"])[0]
+    # pressure: bias 0 and consistency 0 (hmvec.py:545)
+    h.get_power_2halo("y", verbose=True)
+    out = capsys.readouterr().out
+    assert out.count("Check the consistency relation for tSZ") == 2
+    _, cy, _, _ = h.two_halo_terms("y")
+    assert np.all(cy == 0.0)

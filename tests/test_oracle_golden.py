@@ -141,3 +141,34 @@ def test_limber(alpha_table):
                               bg.comoving_radial_distance(lz), float(g["in_omm0"]))
     ckg = hmref.limber_integral(g["ells"], zs, ks, Pgm, gz, Wg, 1.0, bg.h_of_z(gz), bg.comoving_radial_distance(gz))
     assert rel_err(ckg, g["C_kg"]) < 1e-12
+
+
+def test_second_tracers_and_tsz_projections(alpha_table):
+    """case_d: the 1-halo term of two DIFFERENT HOD names / two different pressure names takes the square
+    term of the first name only (hmvec/hmvec.py:510-513) - order-dependent by tens of per cent - and the
+    tSZ Limber projections C_yy / C_ky (hmvec/cosmology.py:585-597)."""
+    g = load_golden("case_d")
+    om, p, meta = build_oracle(g, alpha_table)
+    add_everything(om, g, p, meta)
+    zs, ks = g["zs"], g["ks"]
+    om.add_hod("g2", mthresh=10 ** 11.0 + zs * 0.0, corr="min")
+    sigT = sc.physical_constants["Thomson cross section"][0]
+    me = sc.physical_constants["electron mass"][0] / p["mSun"]
+    fit2 = dict(battaglia_defaults["pres"], P0_A0=25.0, xc_A0=0.6)
+    om.add_battaglia_pres_profile("y2", p["battaglia_pres_alpha"], -0.4, fit2, meta["nxs"], meta["xmax"], sigT, me, sc.c)
+    assert np.max(np.abs(g["P1h_g_g2"] / g["P1h_g2_g"] - 1)) > 0.1      # the fixture does exercise the rule
+    for a, b in (("g", "g2"), ("g2", "g"), ("y", "y2"), ("y2", "y")):
+        ok, w = power_close(om.get_power_1halo(a, b), g[f"P1h_{a}_{b}"])
+        assert ok, (a, b, w)
+        ok, w = power_close(om.get_power_2halo(a, b), g[f"P2h_{a}_{b}"])
+        assert ok, (a, b, w)
+    from hmvec_amd.background import AnalyticBackground
+    bg = AnalyticBackground(p["H0"], p["ombh2"], p["omch2"])
+    chis, hz = bg.comoving_radial_distance(zs), bg.h_of_z(zs)
+    lz = meta["limber"]["lzs"]
+    W = hmref.lensing_window(zs, lz, bg.h_of_z(0.0), hz, chis, bg.comoving_radial_distance(lz), float(g["in_omm0"]))
+    Pyy = g["P1h_y_y"] + g["P2h_y_y"]
+    Pym = g["P1h_nfw_y"] + g["P2h_nfw_y"]
+    one = np.ones(zs.size)
+    assert rel_err(hmref.limber_integral(g["ells"], zs, ks, Pyy, zs, one, one, hz, chis), g["C_yy"]) < 1e-12
+    assert rel_err(hmref.limber_integral(g["ells"], zs, ks, Pym, zs, W, one, hz, chis), g["C_ky"]) < 1e-12

@@ -125,13 +125,13 @@ def cosmo_inputs(h, zs):
 
 def run_case(hm, tag, zs, ks, ms, *, params=None, mass_function="sheth-torman", mdef="vir",
              family="AGN", nxs=512, xmax=20.0, corr="max", ngal_mode=False,
-             central=False, pres=True, numeric_nfw=None, batt_override=None, limber=None):
+             central=False, pres=True, numeric_nfw=None, batt_override=None, limber=None, second_tracers=False):
     params = dict(params or {})
     out = dict(zs=zs, ks=ks, ms=ms)
     meta = dict(params=params, mass_function=mass_function, mdef=mdef, family=family,
                 nxs=nxs, xmax=xmax, corr=corr, ngal_mode=ngal_mode, central=central,
                 pres=pres, numeric_nfw=numeric_nfw, batt_override=batt_override,
-                limber=limber)
+                limber=limber, second_tracers=second_tracers)
     h = hm.HaloModel(zs, ks, ms=ms, params=dict(params), mass_function=mass_function,
                      mdef=mdef, accuracy="low")
     for k, v in cosmo_inputs(h, zs).items():
@@ -184,6 +184,16 @@ def run_case(hm, tag, zs, ks, ms, *, params=None, mass_function="sheth-torman", 
     out["P2h_g_nfw_bin"] = h.get_power_2halo("g", "nfw", b1_in=b1, b2_in=b2)
     out["P_tot_g_electron"] = h.get_power("g", "electron")
 
+    if second_tracers:
+        # two DIFFERENT HOD names / two different pressure names: the 1-halo term takes the square
+        # term of the FIRST name only (hmvec/hmvec.py:510-513), so the result depends on the order
+        h.add_hod("g2", mthresh=10 ** 11.0 + zs * 0.0, corr="min" if corr == "max" else "max")
+        h.add_battaglia_pres_profile("y2", param_override=dict(P0_A0=25.0, xc_A0=0.6, battaglia_pres_gamma=-0.4),
+                                     nxs=nxs, xmax=xmax)
+        for a, b in (("g", "g2"), ("g2", "g"), ("y", "y2"), ("y2", "y")):
+            out[f"P1h_{a}_{b}"] = h.get_power_1halo(a, b)
+            out[f"P2h_{a}_{b}"] = h.get_power_2halo(a, b)
+
     if limber is not None:
         ells = np.asarray(limber["ells"], dtype=float)
         Pmm = out["P1h_nfw_nfw"] + out["P2h_nfw_nfw"]
@@ -198,6 +208,11 @@ def run_case(hm, tag, zs, ks, ms, *, params=None, mass_function="sheth-torman", 
         out["C_kg_dndz"] = h.C_kg(ells, zs, ks, Pgm, gzs=gz, gdndz=gd, lzs=limber["lzs"])
         out["C_gg_dndz"] = h.C_gg(ells, zs, ks, Pgg, gzs=gz, gdndz=gd)
         out["lensing_window"] = h.lensing_window(zs, limber["lzs"])
+        if pres:      # tSZ projections (hmvec/cosmology.py:585-597)
+            Pyy = out["P1h_y_y"] + out["P2h_y_y"]
+            Pym = out["P1h_nfw_y"] + out["P2h_nfw_y"]
+            out["C_yy"] = h.C_yy(ells, zs, ks, Pyy)
+            out["C_ky"] = h.C_ky(ells, zs, ks, Pym, lzs1=limber["lzs"])
     out["meta_json"] = np.array(json.dumps(meta, default=lambda o: np.asarray(o).tolist()))
     return out
 
@@ -351,6 +366,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--skip-readme", action="store_true")
+    ap.add_argument("--only", default=None, help="comma-separated fixture names to (re)generate")
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present; goldens can only be generated in the build container")
@@ -362,34 +378,51 @@ def main():
     install_limber_shims()
     os.makedirs(args.out, exist_ok=True)
 
+    only = set(args.only.split(",")) if args.only else None
+
+    def want(name):
+        return only is None or name in only
+
     def save(name, d):
         path = os.path.join(args.out, name + ".npz")
         np.savez_compressed(path, **d)
         print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
 
-    save("unit_pins", run_unit_pins(hm))
-    save("func_pins", run_function_pins(hm))
+    if want("unit_pins"):
+        save("unit_pins", run_unit_pins(hm))
+    if want("func_pins"):
+        save("func_pins", run_function_pins(hm))
 
     ks = np.geomspace(1e-4, 100, 40)
     ms = np.geomspace(2e10, 1e17, 32)
     # A: defaults (ST, vir, AGN, corr=max, mthresh); z grid has z=0, both SHMR branches, z=3.0
-    save("case_a", run_case(hm, "a", np.array([0.0, 0.5, 1.2, 3.0]), ks, ms, nxs=1000,
-                            numeric_nfw=(4000, 50.0),
-                            limber=None))
+    if want("case_a"):
+        save("case_a", run_case(hm, "a", np.array([0.0, 0.5, 1.2, 3.0]), ks, ms, nxs=1000,
+                                numeric_nfw=(4000, 50.0),
+                                limber=None))
     # B: tinker + mean + SH + corr=min + ngal bisection + miscentred central + odd sigma2_numks
-    save("case_b", run_case(hm, "b", np.array([0.1, 0.8, 1.7, 3.0, 3.4]),
-                            np.geomspace(2e-4, 50, 33), np.geomspace(1e11, 5e15, 24),
-                            params=dict(sigma2_numks=2001, omch2=0.125, H0=70.0, ns=0.97),
-                            mass_function="tinker", mdef="mean", family="SH", nxs=600,
-                            xmax=15.0, corr="min", ngal_mode=True, central=True,
-                            batt_override=dict(battaglia_gas_gamma=-0.25, rho0_A0=4100.0)))
+    if want("case_b"):
+        save("case_b", run_case(hm, "b", np.array([0.1, 0.8, 1.7, 3.0, 3.4]),
+                                np.geomspace(2e-4, 50, 33), np.geomspace(1e11, 5e15, 24),
+                                params=dict(sigma2_numks=2001, omch2=0.125, H0=70.0, ns=0.97),
+                                mass_function="tinker", mdef="mean", family="SH", nxs=600,
+                                xmax=15.0, corr="min", ngal_mode=True, central=True,
+                                batt_override=dict(battaglia_gas_gamma=-0.25, rho0_A0=4100.0)))
     # C: Limber fixtures (no z=0: chi=0 makes the reference NaN), ST/vir
-    save("case_c", run_case(hm, "c", np.linspace(0.05, 3.0, 9), np.geomspace(1e-4, 100, 48),
-                            np.geomspace(2e10, 1e17, 28), nxs=400, pres=False,
-                            params=dict(sigma2_numks=4000),
-                            limber=dict(ells=np.linspace(100, 6000, 12), lzs=2.5, gzs=0.8)))
+    if want("case_c"):
+        save("case_c", run_case(hm, "c", np.linspace(0.05, 3.0, 9), np.geomspace(1e-4, 100, 48),
+                                np.geomspace(2e10, 1e17, 28), nxs=400, pres=False,
+                                params=dict(sigma2_numks=4000),
+                                limber=dict(ells=np.linspace(100, 6000, 12), lzs=2.5, gzs=0.8)))
+    # D: pressure + Limber (C_yy, C_ky) and the first-name-only rule for two HODs / two pressure profiles
+    if want("case_d"):
+        save("case_d", run_case(hm, "d", np.linspace(0.1, 2.8, 7), np.geomspace(1e-4, 100, 44),
+                                np.geomspace(2e10, 1e17, 26), nxs=400, pres=True, second_tracers=True,
+                                params=dict(sigma2_numks=3000),
+                                limber=dict(ells=np.linspace(100, 6000, 10), lzs=2.5, gzs=0.8)))
     if not args.skip_readme:
-        save("readme_c1", run_readme_anchor(hm))
+        if want("readme_c1"):
+            save("readme_c1", run_readme_anchor(hm))
 
 
 if __name__ == "__main__":
