@@ -1437,30 +1437,44 @@ struct BatchArgs {
     int nm, nk;
 };
 
-template <int NT, int NTR, int V>
-__global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
-    extern __shared__ double red[];  // [MS][V][64] per accumulator, reused
+// Summation order over the mass axis (fixed by nm alone, so that a z-slab run and the full grid agree
+// bit for bit whatever launch shape each picks): PB_NV = 16 virtual slices, slice v = the bins
+// m = v, v+16, v+32, ... summed in that order from zero; then the pair sums t_w = s_w + s_{w+8};
+// then t_0 + t_1 + ... + t_7 in that order.  Two launch shapes realise it:
+//   W16 = false: 8 wavefronts (512 threads), wavefront w walks slice w, parks the sums in its private
+//                part of LDS (no barrier), walks slice w+8 and adds the parked sums at the end;
+//   W16 = true : 16 wavefronts (1024 threads), one slice each - twice the loads in flight per CU,
+//                which is what a thin z-slab (one workgroup per CU) needs.
+constexpr int PB_NV = 16;
+
+template <int NT, int NTR, int V, bool W16>
+__global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs A) {
+    extern __shared__ double red[];  // [8][NACC*V][64]: parked sums / pair exchange, then the cross-wave reduction
     using vec_t = typename VecT<V>::type;
     constexpr int NC1 = 1 + NT;
     constexpr int STRIDE = 2 + NTR * 3 * NC1;
     constexpr int NPAIR = NTR * (NTR + 1) / 2;
+    constexpr int NACC = NTR + NPAIR;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int MS = blockDim.x >> 6;
     const int z = blockIdx.y;
     const int k0 = (blockIdx.x * 64 + lane) * V;
     const bool live = k0 < A.nk;
-    double I[NTR][V], P[NPAIR][V];
+    double acc[NACC][V];      // [0, NTR): 2-halo integrals I_t; [NTR, NACC): 1-halo integrals of the pairs
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int t = 0; t < NTR; ++t) I[t][v] = 0.0;
-#pragma unroll
-        for (int p = 0; p < NPAIR; ++p) P[p][v] = 0.0;
-    }
+        for (int v = 0; v < V; ++v) acc[a][v] = 0.0;
     const size_t zrow = (size_t)z * A.nm;
     const int kend = min(A.nk, (int)(blockIdx.x + 1) * 64 * V);   // one past the last k of this tile
     const size_t kofs = live ? (size_t)k0 : 0;   // dead lanes re-read column 0 (their sums are never stored)
+    // the bins of this wavefront, in order: position i -> mass bin (>= nm: no such bin)
+    const int L = (A.nm + PB_NV - 1) / PB_NV;            // positions per slice
+    const int NB = W16 ? L : 2 * L;
+    auto bin = [&](int i) {
+        if (W16) return wv + PB_NV * i;
+        return i < L ? wv + PB_NV * i : wv + 8 + PB_NV * (i - L);
+    };
     // constant-prefix hint of mass bin m: how many leading k of the row equal `val`
     struct Hint { int n[NT]; double val[NT]; };
     auto load_hint = [&](Hint& h, int m) {
@@ -1480,7 +1494,19 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
             else dst[i] = vload_nt<V>(A.tens[i] + off);
         }
     };
-    auto accumulate = [&](const vec_t (&t)[NT], int m) {
+    auto park = [&]() {      // end of the first slice (8-wavefront shape): sums to LDS, start again from zero
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                red[((wv * NACC + a) * V + v) * 64 + lane] = acc[a][v];
+                acc[a][v] = 0.0;
+            }
+    };
+    auto accumulate = [&](const vec_t (&t)[NT], int i) {
+        if (!W16 && i == L) park();
+        const int m = bin(i);
+        if (m >= A.nm) return;
         const double* __restrict__ c = A.coef + (zrow + m) * (size_t)STRIDE;
         const double wn = c[0], wnb = c[1];
 #pragma unroll
@@ -1491,71 +1517,91 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
                 const double* cr = c + 2 + r * 3 * NC1;
                 double w = cr[0], a1 = cr[NC1], a2 = cr[2 * NC1];
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const double tv = vget<V>(t[i], v);
-                    w += cr[1 + i] * tv;
-                    a1 += cr[NC1 + 1 + i] * tv;
-                    a2 += cr[2 * NC1 + 1 + i] * tv;
+                for (int i2 = 0; i2 < NT; ++i2) {
+                    const double tv = vget<V>(t[i2], v);
+                    w += cr[1 + i2] * tv;
+                    a1 += cr[NC1 + 1 + i2] * tv;
+                    a2 += cr[2 * NC1 + 1 + i2] * tv;
                 }
                 W[r] = w; A1[r] = a1; A2[r] = a2;
-                I[r][v] += wnb * w;
+                acc[r][v] += wnb * w;
             }
-            int p = 0;
+            int p = NTR;
 #pragma unroll
             for (int a = 0; a < NTR; ++a) {
-                P[p][v] += wn * (A1[a] * A2[a]);
+                acc[p][v] += wn * (A1[a] * A2[a]);
                 ++p;
 #pragma unroll
                 for (int b = a + 1; b < NTR; ++b) {
-                    P[p][v] += wn * (W[a] * W[b]);
+                    acc[p][v] += wn * (W[a] * W[b]);
                     ++p;
                 }
             }
         }
     };
-    // Two-stage software pipeline over this wavefront's mass bins (m, m+MS, ...): the loads of the
-    // next bin are in flight while the current one is consumed, and the hints run one bin further
-    // ahead so that a fetch never waits for its own decision.  The scheduling barriers keep hipcc
-    // from sinking the early loads back down to their first use.
-    int m = wv;
+    // Two-stage software pipeline over this wavefront's bins: the loads of the next bin are in flight
+    // while the current one is consumed, and the hints run one bin further ahead so that a fetch never
+    // waits for its own decision.  The scheduling barriers keep hipcc from sinking the early loads back
+    // down to their first use.
+    int i = 0;
     vec_t ta[NT], tb[NT];
     Hint ha, hb;
-    load_hint(ha, m);
-    load_hint(hb, m + MS);
-    fetch(ta, m, ha);
+    load_hint(ha, bin(0));
+    load_hint(hb, bin(1));
+    fetch(ta, bin(0), ha);
 #pragma unroll 1
-    for (; m + MS < A.nm; m += 2 * MS) {
-        fetch(tb, m + MS, hb);
-        load_hint(ha, m + 2 * MS);
+    for (; i + 1 < NB; i += 2) {
+        fetch(tb, bin(i + 1), hb);
+        load_hint(ha, bin(i + 2));
         __builtin_amdgcn_sched_barrier(0);
-        accumulate(ta, m);
+        accumulate(ta, i);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(ta, m + 2 * MS, ha);
-        load_hint(hb, m + 3 * MS);
+        fetch(ta, bin(i + 2), ha);
+        load_hint(hb, bin(i + 3));
         __builtin_amdgcn_sched_barrier(0);
-        accumulate(tb, m + MS);
+        accumulate(tb, i + 1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (m < A.nm) accumulate(ta, m);
-    // cross-wave reduction through LDS, one accumulator at a time (keeps LDS at MS*V*512 B)
-    auto reduce = [&](double (&acc)[V]) {
-        __syncthreads();
+    if (i < NB) accumulate(ta, i);
+    // pair sums t_w = s_w + s_{w+8}
+    if (W16) {
+        if (wv >= 8) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) red[(wv * V + v) * 64 + lane] = acc[v];
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int v = 0; v < V; ++v) red[(((wv - 8) * NACC + a) * V + v) * 64 + lane] = acc[a][v];
+        }
+        __syncthreads();
+    }
+    if (wv < 8) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double other = red[((wv * NACC + a) * V + v) * 64 + lane];
+                acc[a][v] = W16 ? acc[a][v] + other : other + acc[a][v];     // s_w + s_{w+8}
+            }
+    }
+    // ordered sum over the eight pair sums through LDS, one accumulator at a time (the parked values have
+    // been consumed: the same memory serves as [8][V][64] exchange buffer)
+    auto reduce = [&](double (&x)[V]) {
+        __syncthreads();
+        if (wv < 8) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) red[(wv * V + v) * 64 + lane] = x[v];
+        }
         __syncthreads();
         if (wv == 0) {
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                double s = 0.0;
-                for (int w = 0; w < MS; ++w) s += red[(w * V + v) * 64 + lane];
-                acc[v] = s;
+                double sum = 0.0;
+                for (int w = 0; w < 8; ++w) sum += red[(w * V + v) * 64 + lane];
+                x[v] = sum;
             }
         }
     };
 #pragma unroll
-    for (int t = 0; t < NTR; ++t) reduce(I[t]);
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) reduce(P[p]);
+    for (int a = 0; a < NACC; ++a) reduce(acc[a]);
     if (wv == 0 && live) {
         double bmc[NTR];  // b_t - C_t
 #pragma unroll
@@ -1581,8 +1627,8 @@ __global__ __launch_bounds__(512) void power_batch_kernel(BatchArgs A) {
             for (int a = 0; a < NTR; ++a) {
 #pragma unroll
                 for (int b = a; b < NTR; ++b) {
-                    if (A.P1h[p]) A.P1h[p][o] = P[p][v] * damp;
-                    if (A.P2h[p]) A.P2h[p][o] = plin * (I[a][v] + bmc[a]) * (I[b][v] + bmc[b]);
+                    if (A.P1h[p]) A.P1h[p][o] = acc[NTR + p][v] * damp;
+                    if (A.P2h[p]) A.P2h[p][o] = plin * (acc[a][v] + bmc[a]) * (acc[b][v] + bmc[b]);
                     ++p;
                 }
             }
@@ -2660,14 +2706,18 @@ int hmg_power_2halo_terms(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* 
     return power_impl(c, nz, nm, nk, ta, tb, nzm, bh, ms, wm, ks, nullptr, rho_m0, 1.0, nullptr, nullptr, I1, I2, C12);
 }
 
-template <int NT, int NTR, int V>
-static int launch_power_batch(hmg_ctx* c, const BatchArgs& A, int nz, int ms_split) {
+template <int NT, int NTR, int V, bool W16>
+static int launch_power_batch(hmg_ctx* c, const BatchArgs& A, int nz) {
     const int per_block = 64 * V;
     dim3 grid((A.nk + per_block - 1) / per_block, nz);
-    const size_t lds = (size_t)ms_split * V * 64 * sizeof(double);
+    constexpr int NACC = NTR + NTR * (NTR + 1) / 2;
+    const size_t lds = (size_t)8 * NACC * V * 64 * sizeof(double);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)power_batch_kernel<NT, NTR, V, W16>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int stop = -1;
     if (bracket_open(c, HMG_KERNEL_POWER, &stop)) return 1;
-    hipLaunchKernelGGL((power_batch_kernel<NT, NTR, V>), grid, dim3(64 * ms_split), lds, c->stream, A);
+    hipLaunchKernelGGL((power_batch_kernel<NT, NTR, V, W16>), grid, dim3(W16 ? 1024 : 512), lds, c->stream, A);
     HIP_TRY(hipGetLastError());
     return bracket_close(c, stop);
 }
@@ -2734,14 +2784,16 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     A.coef = coef; A.sidep = sidep; A.ks = ks; A.Pzk = Pzk; A.kstar = kstar; A.nm = nm; A.nk = nk;
     bool vec2 = (nk % 2 == 0);
     for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
-    // thin z-slabs: narrower k tiles so that every CU still gets a workgroup
-    if (vec2 && (long)((nk + 127) / 128) * nz < c->num_cu) vec2 = false;
-    int ms_split = 8;   // fixed (function of nm only): summation order independent of the slab size
-    if (const char* e = getenv("HMG_PB_MS")) ms_split = atoi(e);
-    REQUIRE(ms_split >= 1 && ms_split <= 8, "HMG_PB_MS must be 1..8");
-    while (ms_split > 1 && ms_split > nm) ms_split >>= 1;
-#define PB_V(NT_, NTR_) return vec2 ? launch_power_batch<NT_, NTR_, 2>(c, A, nz, ms_split) \
-                                    : launch_power_batch<NT_, NTR_, 1>(c, A, nz, ms_split);
+    // thin z-slabs: narrower k tiles so that every CU still gets a workgroup, and sixteen wavefronts per
+    // workgroup (one per virtual mass slice) so that each CU keeps twice the loads in flight.  The
+    // summation order is the same in both shapes (see power_batch_kernel).
+    bool thin = (long)((nk + 127) / 128) * nz < c->num_cu;
+    if (const char* e = getenv("HMG_PB_THIN")) thin = atoi(e) != 0;      // tuning/testing: force a shape
+    if (thin) vec2 = false;
+#define PB_V(NT_, NTR_)                                                              \
+    return thin ? launch_power_batch<NT_, NTR_, 1, true>(c, A, nz)                   \
+                : (vec2 ? launch_power_batch<NT_, NTR_, 2, false>(c, A, nz)          \
+                        : launch_power_batch<NT_, NTR_, 1, false>(c, A, nz));
 #define PB_NTR(NT_)                         \
     switch (ntr) {                          \
         case 1: PB_V(NT_, 1)                \

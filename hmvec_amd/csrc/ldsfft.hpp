@@ -139,13 +139,10 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twste
     const int k = j - (int)fast_div((unsigned)j, magic) * Ns;      // j mod Ns
     const int stride = M / R;
     v[0] = buf[j];
-    if (k == 0) {
-#pragma unroll
-        for (int t = 1; t < R; ++t) v[t] = buf[j + t * stride];
-        return;
-    }
     // one table read (w = W^(k M/(Ns R))); the higher powers by complex multiplication
-    // (<= 3 products, a few ulp) instead of R-1 dependent trips to the L2-resident table
+    // (<= 3 products, a few ulp) instead of R-1 dependent trips to the L2-resident table.
+    // k == 0 is not special-cased: its twiddle is twM[0] = 1 exactly, and a branch would make
+    // every wavefront that holds such a lane walk both paths.
     const cplx w1 = twM[k * twstep];
     cplx w = w1;
 #pragma unroll
