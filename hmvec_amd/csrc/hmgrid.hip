@@ -825,14 +825,21 @@ struct FusedArgs {
     double* out;
     int* nconst;               // optional constant-prefix hint per row
     double* cconst;
+    const double* logx;        // ln xs[n], shared by every row (nullptr: evaluated per sample)
 };
+
+// ln x_n of the radial grid: the same for all (z,m) rows, so with many rows one small launch replaces a
+// quarter of the integrand's transcendentals (same log_fast as the in-kernel path: identical bits).
+__global__ void logx_kernel(int n, const double* __restrict__ xs, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log_fast(xs[i]);
+}
 
 // amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two
 // powers of t) with the short fp64 log/exp/log1p of fastmath.hpp (< 2 ulp each, host-tested):
 // ~100 VALU ops per sample instead of ~190 with the device library's and ~700 with three pow().
-__device__ __forceinline__ double gnfw_rho_fast(double x, double A, double inv_xc, double AL,
-                                                double EX, double gamma) {
-    const double lt = log_fast(x * inv_xc);
+__device__ __forceinline__ double gnfw_rho_fast(double lt /* ln(x/xc) */, double A, double AL, double EX,
+                                                double gamma) {
     const double ta = exp_fast(fmin(AL * lt, 700.0));
     return A * exp_fast(gamma * lt - EX * log1p_fast(ta));
 }
@@ -878,7 +885,7 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
     const double EX = A.expo ? A.expo[row] : A.expo_c;
     const double cm = A.cmax[row];
-    const double inv_xc = 1.0 / XC;
+    const double ln_xc = log_fast(XC);          // ln(x/xc) = ln x - ln xc: ln x is row-independent
     // Output side of the row: the FFT modes sit on the uniform grid kout_j = j k_lo,
     // k_lo = kt_1 / (r_s (1+z)).  Targets below k_lo take np.interp's left fill u_1, targets above
     // kout_M are zero, and only the modes j <= jn = floor(max(ks)/k_lo) + 2 can be reached at all:
@@ -907,8 +914,8 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
         const int j = 2 * p;
         const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
         double r0 = 0.0, r1 = 0.0;
-        if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(xv.x, Aamp, inv_xc, AL, EX, A.gamma);
-        if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(xv.y, Aamp, inv_xc, AL, EX, A.gamma);
+        if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
+        if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
         const cplx y = cplx{xv.x * r0, xv.y * r1};
         if (pruned) {
             for (int t = 0; t < R0; ++t) buf[R0 * p + t] = y;
@@ -2542,8 +2549,16 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
             A.amp_c = amp_c; A.xc_c = xc_c; A.alpha_c = alpha_c; A.expo_c = expo_c; A.gamma = gamma;
             A.step = step; A.cmax = cmax; A.rss = rss; A.zs = zs; A.ks = ks; A.post = post; A.out = out;
             A.nconst = nconst; A.cconst = cconst;
+            A.logx = nullptr;
             int stop = -1;
             if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
+            if (rows >= 8192) {      // enough rows for the table's own launch to pay (MI355X: -1 % at 16384 rows, +2 % at 4096)
+                if (ensure_scratch(c, 2, (size_t)nxs * 8)) return 1;
+                hipLaunchKernelGGL(logx_kernel, grid1d((size_t)nxs, 256), dim3(256), 0, c->stream, nxs, xs,
+                                   (double*)c->scratch[2]);
+                HIP_TRY(hipGetLastError());
+                A.logx = (const double*)c->scratch[2];
+            }
             int rc;
             const int mb = FP->maxb, mp = FP->maxp;
             if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
@@ -2787,13 +2802,13 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     // thin z-slabs: narrower k tiles so that every CU still gets a workgroup, and sixteen wavefronts per
     // workgroup (one per virtual mass slice) so that each CU keeps twice the loads in flight.  The
     // summation order is the same in both shapes (see power_batch_kernel).
-    bool thin = (long)((nk + 127) / 128) * nz < c->num_cu;
-    if (const char* e = getenv("HMG_PB_THIN")) thin = atoi(e) != 0;      // tuning/testing: force a shape
+    int thin = (long)((nk + 127) / 128) * nz < c->num_cu ? 1 : 0;
+    if (const char* e = getenv("HMG_PB_THIN")) thin = atoi(e);      // tuning/testing: force a shape (2: V=1, 8 wavefronts)
     if (thin) vec2 = false;
 #define PB_V(NT_, NTR_)                                                              \
-    return thin ? launch_power_batch<NT_, NTR_, 1, true>(c, A, nz)                   \
-                : (vec2 ? launch_power_batch<NT_, NTR_, 2, false>(c, A, nz)          \
-                        : launch_power_batch<NT_, NTR_, 1, false>(c, A, nz));
+    return thin == 1 ? launch_power_batch<NT_, NTR_, 1, true>(c, A, nz)              \
+                     : (vec2 ? launch_power_batch<NT_, NTR_, 2, false>(c, A, nz)     \
+                             : launch_power_batch<NT_, NTR_, 1, false>(c, A, nz));
 #define PB_NTR(NT_)                         \
     switch (ntr) {                          \
         case 1: PB_V(NT_, 1)                \

@@ -600,9 +600,14 @@ class HaloModel(Cosmology):
                             {"max": 0, "min": 1}[corr])
         thr = np.ascontiguousarray(log10mstar_thresh, dtype=np.float64)
         cached = self._dcache.get(("thr", key))
-        if cached is None or not np.array_equal(cached[0], thr):
+        if cached is None or cached[0].shape != thr.shape:
             cached = (thr.copy(), ctx.upload(thr))
             self._dcache[("thr", key)] = cached
+        elif not np.array_equal(cached[0], thr):
+            # new thresholds go into the SAME device buffer (stream-ordered behind the launches that
+            # read the old ones): nothing is freed, so nothing synchronises the other lanes
+            nat.check(ctx.lib.hmg_memcpy_h2d(ctx.handle, cached[1].ptr, thr.ctypes.data, thr.nbytes))
+            cached[0][...] = thr
         d_thr = cached[1]
         out = {k: self._buf((key, k), (nz, nm)) for k in ("Nc", "Ns", "NsNsm1", "NcNs")}
         out["ngal"], out["bg"] = self._buf((key, "ngal"), (nz,)), self._buf((key, "bg"), (nz,))

@@ -33,8 +33,11 @@ def test_single_rank_communicator_roundtrip(tmp_path, monkeypatch):
 def test_gather_overlaps_on_its_own_lane_and_stays_ordered(tmp_path, monkeypatch):
     """ShardedSpectra issues the all-gather on the communication lane behind an event so that the next
     pass overlaps it.  With a 1-rank communicator the gather is a copy, which is enough to check the
-    ordering: after several back-to-back passes (no host synchronisation) with a model that changes in
-    between, the gathered buffers hold exactly the spectra of the LAST pass."""
+    ordering: after several back-to-back passes with a model that changes in between, the gathered
+    buffers hold exactly the spectra of the LAST pass.  Between passes the host only waits for the small
+    threshold upload on the COMPUTE lane (same device buffer every time: nothing is freed, so no
+    all-lane synchronisation happens) - the communication lane is never waited for inside the loop, so
+    the gather of pass N really is in flight while pass N+1 is enqueued."""
     import hmvec_amd as hm
     from hmvec_amd import _native as nat
     from hmvec_amd.dist import RcclComm, ShardedSpectra
@@ -50,7 +53,7 @@ def test_gather_overlaps_on_its_own_lane_and_stays_ordered(tmp_path, monkeypatch
     spec = ShardedSpectra(h, comm, zs.size, pairs, force_gather=True)
     assert spec.full[0] is not spec.local[0]
     thresholds = [10.2, 10.6, 11.0, 11.4, 10.4]
-    for t in thresholds:                                   # no host synchronisation inside the loop
+    for t in thresholds:                                   # the communication lane is not synchronised in here
         h.add_hod("g", mthresh=10 ** t + zs * 0.0, ignore_existing=True)
         spec.run()
     comm.barrier()
