@@ -180,7 +180,7 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
                      "threadpools": pools})
     if allcore and avail > 1:
         nproc = 1
-        for cand in (32, 16, 8, 4, 2):      # a divisor of nz that fits the cores we may use
+        for cand in (16, 8, 4, 2):          # a divisor of nz within the box's CPU share for one GPU (16)
             if cand <= avail and zs.size % cand == 0:
                 nproc = cand
                 break
