@@ -460,6 +460,10 @@ __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
 constexpr int NFW_NS = 16;     // terms used for (1+c) x <= 4
 constexpr int NFW_NS2 = 32;    // terms used for 4 < (1+c) x <= NFW_X2 (same coefficient row, first 16 shared)
 constexpr double NFW_X2 = 10.0;
+constexpr int NFW_NT1 = 5;          // terms for (1+c) x <= NFW_XS1
+constexpr double NFW_XS1 = 0.1;
+constexpr int NFW_NT2 = 8;          // terms for (1+c) x <= NFW_XS2
+constexpr double NFW_XS2 = 0.8;
 // With 32 terms the series stays within 3e-15 (absolute, against 50-digit arithmetic, c in [0.5, 100])
 // up to (1+c) x = 10: the band 4 < (1+c) x <= 10 - where x itself is still on the small-argument
 // branch of Si/Ci, the most expensive case of the closed form - costs 32 FMAs instead.
@@ -488,7 +492,12 @@ __global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, doubl
 }
 
 // ktile = k values per workgroup (a multiple of the block size)
-__global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ T,
+// 6 waves/SIMD (80 VGPRs, a few spills in the rare closed-form path) beats the 4-5 the compiler picks
+// on its own and the 8 that spill in the hot paths: 0.167 / 0.160 / 0.179 ms (MI355X, Config 3).
+#ifndef HMG_NFW_OCC
+#define HMG_NFW_OCC 6
+#endif
+__global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* __restrict__ T,
                                                   const double* __restrict__ acoef, int ktile, int nm, int nk,
                                                   const double* __restrict__ cs,
                                                   const double* __restrict__ rss,
@@ -518,10 +527,24 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
         const double x = ks[k] * rs * z1;
         const double xc = opc * x;
         if (use_series && xc <= 4.0) {
+            // The series alternates and its n-th term is below (xc)^(2n) / (2n (2n+1)! m_c): 5 terms are
+            // exact to 1e-18 for (1+c) x <= 0.1, 8 terms to 2e-17 for <= 0.8 - about 60 % of a typical
+            // grid (k starts four decades below the halo scale) takes one of the two short forms.
             const double z = x * x;
-            double u = fma_svs(a[NFW_NS - 1], z, a[NFW_NS - 2]);
+            double u;
+            if (xc <= NFW_XS1) {
+                u = fma_svs(a[NFW_NT1 - 1], z, a[NFW_NT1 - 2]);
 #pragma unroll
-            for (int n = NFW_NS - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
+                for (int n = NFW_NT1 - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
+            } else if (xc <= NFW_XS2) {
+                u = fma_svs(a[NFW_NT2 - 1], z, a[NFW_NT2 - 2]);
+#pragma unroll
+                for (int n = NFW_NT2 - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
+            } else {
+                u = fma_svs(a[NFW_NS - 1], z, a[NFW_NS - 2]);
+#pragma unroll
+                for (int n = NFW_NS - 3; n >= 0; --n) u = fma_vvs(u, z, a[n]);
+            }
             __builtin_nontemporal_store(u, &dst[k]);
             continue;
         }
@@ -548,6 +571,28 @@ __global__ __launch_bounds__(256) void nfw_kernel(const SiciTable* __restrict__ 
             __builtin_nontemporal_store((g1 + (f2 - xc * zc) * sd - g2 * cd) * inv_mc, &dst[k]);
             continue;
         }
+        if (x <= 4.0 && xc > 8.0) {
+            // Mixed band (3.5 % of a typical grid, beyond the reach of the series): x on the rational
+            // branch of Si/Ci, (1+c)x on the auxiliary-function branch.  Substituting
+            // Si(xc) = pi/2 - f cos xc - g sin xc, Ci(xc) = f sin xc - g cos xc and xc - x = c x,
+            //     u m_c = (pi/2) sin x + f(xc) sin(cx) - g(xc) cos(cx) - sin(cx)/xc - sin x Si(x) - cos x Ci(x):
+            // sincos of x and c x (the reference's own arguments) instead of x and xc, two rational
+            // pairs instead of four, one short logarithm.
+            double s1, c1, sd, cd, f2, g2;
+            sincos_fast(x, s1, c1);
+            sincos_fast(c * x, sd, cd);
+            const double x2 = x * x;
+            const double zc = rcp_fast(x2) * inv_opc2;                   // 1/xc^2
+            const double sden = horner_s<6>(x2, T->SD), cden = horner_s<6>(x2, T->CD);
+            const double r = rcp_fast(sden * cden);
+            const double si = x * horner_s<6>(x2, T->SN) * (cden * r);
+            const double ci = (EULER_GAMMA + log_fast(x)) + x2 * horner_s<6>(x2, T->CN) * (sden * r);
+            sici_aux<true>(T, xc, zc, f2, g2);
+            __builtin_nontemporal_store((HALF_PI * s1 + (f2 - xc * zc) * sd - g2 * cd - s1 * si - c1 * ci) * inv_mc,
+                                        &dst[k]);
+            continue;
+        }
+        // everything else (rows with c < 0.5, arguments beyond 1e9): the closed form as the reference writes it
         double s1, c1, s2, c2;
         if (xc < 1.0e9) {
             sincos_fast(x, s1, c1);
