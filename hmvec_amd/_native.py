@@ -47,6 +47,7 @@ PROF_BATTAGLIA_GAS, PROF_BATTAGLIA_PRES = 1, 2
 TRACER_MATTER, TRACER_HOD, TRACER_PRESSURE = 0, 1, 2
 KERNEL_POWER, KERNEL_NFW, KERNEL_PROFILE_FFT = 0, 1, 2
 EVENT_SLOTS = 4096
+NFW_SERIES_STRIDE = 36     # HMG_NFW_SERIES_STRIDE
 
 _I, _D, _P, _Z = C.c_int, C.c_double, C.c_void_p, C.c_size_t
 # name -> argtypes (restype is int for all but hmg_last_error); mirrors include/hmgrid.h
@@ -77,6 +78,7 @@ SIGNATURES = {
     "hmg_sigma2_layout_size": [_I, _I, C.POINTER(_Z)],
     "hmg_sigma2_prepare": [_P, _I, _I, _P, _P],
     "hmg_sigma2_prepared": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P],
+    "hmg_sigma2_massfn": [_P, _I, _I, _I, _P, _P, _P, _P, _D, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P],
     "hmg_halo_stage": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P, _P, _P, _D, _P, _P, _P],
     "hmg_massfn": [_P, _I, _I, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P],
     "hmg_halo_structure": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P],
@@ -87,7 +89,8 @@ SIGNATURES = {
     "hmg_profile_rows_from_mvir": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _D, _P, _P, C.POINTER(_D * 9), _D, _D,
                                    _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hmg_profile_fft": [_P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D, _D,
-                        _P, _P, _P, _P, _I, _P, _P, _P, _P],
+                        _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "hmg_profile_fft_logx": [_P, _I, _P, _P],
     "hmg_hod": [_P, _I, _I, C.POINTER(HodParams), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hmg_power": [_P, _I, _I, _I, C.POINTER(Tracer), C.POINTER(Tracer), _P, _P, _P, _P, _P, _P,
                   _D, _D, _P, _P],

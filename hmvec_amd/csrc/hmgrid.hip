@@ -337,15 +337,12 @@ __device__ __forceinline__ double tinker10_bias(double nu) {
     return 1.0 - A * nua / (nua + pow(dc, a)) + 0.183 * pow(nu, 1.5) + C * pow(nu, 2.4);
 }
 
-__global__ void massfn_kernel(int nz, int nm, MassFnDev P, const double* __restrict__ s2,
-                              const double* __restrict__ ms, const double* __restrict__ lnm,
-                              const double* __restrict__ tz, double* __restrict__ nzm,
-                              double* __restrict__ bh) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nz * nm) return;
-    const int z = idx / nm, m = idx - z * nm;
-    const double* row = s2 + (size_t)z * nm;
-    const double sig2 = row[m];
+// n(z,m) and b(z,m) of one grid point; S(i) returns sigma2[z][i] (from global memory or from LDS)
+template <class SigmaAt>
+__device__ __forceinline__ void massfn_point(const MassFnDev& P, int z, int m, int nm, SigmaAt S,
+                                             const double* __restrict__ ms, const double* __restrict__ lnm,
+                                             const double* __restrict__ tz, double& n_out, double& b_out) {
+    const double sig2 = S(m);
     const double dc = P.deltac;
     double f, b;
     if (P.mode == HMG_MF_SHETH_TORMEN) {
@@ -365,7 +362,7 @@ __global__ void massfn_kernel(int nz, int nm, MassFnDev P, const double* __restr
     }
     // d ln(1/sigma) / d ln m with numpy.gradient's stencils (second order interior,
     // one-sided first order at the ends; uniform-grid shortcut when numpy would take it)
-    auto L = [&](int i) { return -0.5 * log(row[i]); };
+    auto L = [&](int i) { return -0.5 * log(S(i)); };
     double g;
     if (nm == 1) {
         g = 0.0;
@@ -381,8 +378,74 @@ __global__ void massfn_kernel(int nz, int nm, MassFnDev P, const double* __restr
         g = ca * L(m - 1) + cb * L(m) + cc * L(m + 1);
     }
     const double mm = ms[m];
-    nzm[idx] = P.rho_m0 * f * g / (mm * mm);
+    n_out = P.rho_m0 * f * g / (mm * mm);
+    b_out = b;
+}
+
+__global__ void massfn_kernel(int nz, int nm, MassFnDev P, const double* __restrict__ s2,
+                              const double* __restrict__ ms, const double* __restrict__ lnm,
+                              const double* __restrict__ tz, double* __restrict__ nzm,
+                              double* __restrict__ bh) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nz * nm) return;
+    const int z = idx / nm, m = idx - z * nm;
+    const double* row = s2 + (size_t)z * nm;
+    double n, b;
+    massfn_point(P, z, m, nm, [&](int i) { return row[i]; }, ms, lnm, tz, n, b);
+    nzm[idx] = n;
     bh[idx] = b;
+}
+
+// Second stage of sigma^2 (the ordered sum over the k' segments, exactly sigma2_combine_kernel's) and
+// the mass function in ONE launch: a workgroup owns 64 consecutive masses of one redshift, sums the
+// partials of those and of the two neighbours the gradient stencil reaches, keeps the 66 values in
+// LDS, writes sigma2 and evaluates n(z,m), b(z,m) from LDS.  grid (ceil(nm/64), nz), 256 threads.
+__device__ __forceinline__ double sigma2_segment_sum(int n, int parts, const double* __restrict__ partial, size_t i, int w) {
+    double s = 0.0;
+    int p = w;
+    for (; p + 28 < parts; p += 32) {       // loads are independent of the running sum: eight at a time
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + 4 * u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < parts; p += 4) s += partial[(size_t)p * n + i];
+    return s;
+}
+__global__ __launch_bounds__(256) void sigma2_massfn_kernel(int nz, int nm, int parts, MassFnDev P,
+                                                            const double* __restrict__ partial /*[parts][nz*nm]*/,
+                                                            const double* __restrict__ ms,
+                                                            const double* __restrict__ lnm,
+                                                            const double* __restrict__ tz,
+                                                            double* __restrict__ s2, double* __restrict__ nzm,
+                                                            double* __restrict__ bh) {
+    __shared__ double red[4][66];
+    __shared__ double sig[66];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int z = blockIdx.y, m0 = blockIdx.x * 64;
+    const int n = nz * nm;
+    // slot j <-> mass m0 - 1 + j (clamped to the row): lanes take j = lane, lanes 0,1 also j = 64, 65
+    for (int j = lane; j < 66; j += 64) {
+        const int m = min(max(m0 - 1 + j, 0), nm - 1);
+        red[w][j] = sigma2_segment_sum(n, parts, partial, (size_t)z * nm + m, w);
+    }
+    __syncthreads();
+    if (threadIdx.x < 66) {
+        const int j = threadIdx.x;
+        const double v = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+        sig[j] = v;
+        const int m = m0 - 1 + j;
+        if (j >= 1 && j <= 64 && m < nm) s2[(size_t)z * nm + m] = v;
+    }
+    __syncthreads();
+    const int m = m0 + threadIdx.x;
+    if (threadIdx.x < 64 && m < nm) {
+        double nn, bb;
+        massfn_point(P, z, m, nm, [&](int i) { return sig[i - m0 + 1]; }, ms, lnm, tz, nn, bb);
+        nzm[(size_t)z * nm + m] = nn;
+        bh[(size_t)z * nm + m] = bb;
+    }
 }
 
 // ---------------------------------------------------------------- A5: c(m,z), rvir(m,z)
@@ -460,6 +523,7 @@ __global__ void mdelta_kernel(int nz, int nm, const double* __restrict__ ms,
 constexpr int NFW_NS = 16;     // terms used for (1+c) x <= 4
 constexpr int NFW_NS2 = 32;    // terms used for 4 < (1+c) x <= NFW_X2 (same coefficient row, first 16 shared)
 constexpr double NFW_X2 = 10.0;
+constexpr int NFW_ROW = HMG_NFW_SERIES_STRIDE;   // doubles per (z,m) row: 32 series coefficients + row constants
 constexpr int NFW_NT1 = 5;          // terms for (1+c) x <= NFW_XS1
 constexpr double NFW_XS1 = 0.1;
 constexpr int NFW_NT2 = 8;          // terms for (1+c) x <= NFW_XS2
@@ -473,9 +537,16 @@ __device__ __forceinline__ void nfw_series_row(double c, double* __restrict__ a)
     const double mc = log(opc) - c / opc;
     const double inv_mc = 1.0 / mc;
     double jm2 = c / opc, jm1 = mc, cp = c;   // J_0, J_1, c^(p-1) for p = 2
+    a[NFW_NS2 + 0] = log(opc);              // row constants of the closed forms, computed once per row
+    a[NFW_NS2 + 1] = inv_mc;                //   here instead of once per thread of the row's workgroup
+    a[NFW_NS2 + 2] = 1.0 / (opc * opc);
+    a[NFW_NS2 + 3] = 0.0;
     a[0] = (c >= 0.5) ? 1.0 : 0.0;
+    // unrolled: 1/(p-1) becomes a compile-time factor (a division here is ~15 dependent instructions in a
+    // 62-step chain); coefficients stay within 5e-15 of 80-digit arithmetic for c in [0.5, 100]
+#pragma unroll
     for (int p = 2; p < 2 * NFW_NS2; ++p) {
-        const double jp = cp / (double)(p - 1) - 2.0 * jm1 - jm2;
+        const double jp = cp * (1.0 / (double)(p - 1)) - 2.0 * jm1 - jm2;
         cp *= c;
         if (p & 1) {
             const int n = (p - 1) >> 1;
@@ -488,7 +559,7 @@ __device__ __forceinline__ void nfw_series_row(double c, double* __restrict__ a)
 __global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, double* __restrict__ acoef) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
-    nfw_series_row(cs[row], acoef + (size_t)row * NFW_NS2);
+    nfw_series_row(cs[row], acoef + (size_t)row * NFW_ROW);
 }
 
 // ktile = k values per workgroup (a multiple of the block size)
@@ -515,12 +586,9 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* 
     const double rs = rss[row];
     const double z1 = 1.0 + zs[z];
     const double opc = 1.0 + c;
-    const double ln_opc = log(opc);
-    const double mc = ln_opc - c / opc;
-    const double inv_mc = 1.0 / mc;
-    const double inv_opc2 = 1.0 / (opc * opc);
-    // small-argument series coefficients of this row: wave-uniform -> SGPRs
-    const double* __restrict__ a = acoef + (size_t)row * NFW_NS2;
+    // small-argument series coefficients and closed-form constants of this row: wave-uniform -> SGPRs
+    const double* __restrict__ a = acoef + (size_t)row * NFW_ROW;
+    const double ln_opc = a[NFW_NS2 + 0], inv_mc = a[NFW_NS2 + 1], inv_opc2 = a[NFW_NS2 + 2];
     const bool use_series = (a[0] != 0.0);
     double* __restrict__ dst = uk + (size_t)row * nk;
     for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
@@ -708,7 +776,7 @@ __global__ void halo_stage_kernel(int nz, int nm, const double* __restrict__ ms,
         m2[idx] = M2;
         r2[idx] = cbrt(3.0 * M2 / 4.0 / M_PI / delta2 / rho2[z]);
     }
-    if (series) nfw_series_row(c, series + (size_t)idx * NFW_NS2);
+    if (series) nfw_series_row(c, series + (size_t)idx * NFW_ROW);
 }
 
 // ---------------------------------------------------------------- K4: profile integrand (F1)
@@ -2364,6 +2432,34 @@ int hmg_sigma2_prepared(hmg_ctx* c, int nz, int nm, int nq, const double* PT, co
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int hmg_sigma2_massfn(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq, const double* wq,
+                      const double* R, double tswitch, const hmg_massfn_params* p, const double* ms,
+                      const double* lnms, const double* tz, double* sigma2, double* nzm, double* bh) {
+    REQUIRE(c && PT && kq && wq && R && p && ms && lnms && sigma2 && nzm && bh, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
+    REQUIRE(p->mode == HMG_MF_SHETH_TORMEN || p->mode == HMG_MF_TINKER10, "unknown mass function");
+    REQUIRE(p->mode != HMG_MF_TINKER10 || tz, "Tinker mode needs d_tinker_z");
+    REQUIRE(nz <= 65535, "nz too large");
+    const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
+    const int ztile = sigma2_ztile(nz), nzp = sigma2_nzp(nz);
+    if (ensure_scratch(c, 4, (size_t)nseg * nz * nm * 8)) return 1;
+    double* partial = (double*)c->scratch[4];
+    dim3 grid((nm + 15) / 16, nseg, nzp / ztile);
+    REQUIRE(grid.y <= 65535 && grid.z <= 65535, "grid too large");
+    if (ztile == 32)
+        hipLaunchKernelGGL(sigma2_mfma_kernel<2>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
+                           PT, kq, wq, R, tswitch, partial);
+    else
+        hipLaunchKernelGGL(sigma2_mfma_kernel<1>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
+                           PT, kq, wq, R, tswitch, partial);
+    HIP_TRY(hipGetLastError());
+    MassFnDev P{p->mode, p->deltac, p->st_A, p->st_a, p->st_p, p->rho_m0, p->lnm_uniform, p->lnm_step};
+    hipLaunchKernelGGL(sigma2_massfn_kernel, dim3((nm + 63) / 64, nz), dim3(256), 0, c->stream, nz, nm, nseg, P,
+                       (const double*)partial, ms, lnms, tz, sigma2, nzm, bh);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int hmg_sigma2(hmg_ctx* c, int nz, int nm, int nq, const double* sP, const double* kq,
                const double* wq, const double* R, double tswitch, double* out) {
     REQUIRE(c && sP && kq && wq && R && out, "NULL argument");
@@ -2429,7 +2525,9 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
     // 16 k per thread amortise the per-row prologue (a log, two divisions, the scalar loads of the
     // series row); smaller tiles were measured slower at every grid size once the series made the
     // per-point cost small
-    int threads = 256, ktile = 4096;
+    // 128 threads per row once there are enough rows to fill the chip several times over (32 k per thread
+    // amortise the row set-up better: -4 % at 16384 rows, +6 % at 4096)
+    int threads = (size_t)nz * nm >= 12288 ? 128 : 256, ktile = 4096;
     if (const char* e = getenv("HMG_NFW_THREADS")) threads = atoi(e);
     if (const char* e = getenv("HMG_NFW_KTILE")) ktile = atoi(e);
     REQUIRE(threads == 64 || threads == 128 || threads == 256, "HMG_NFW_THREADS must be 64/128/256");
@@ -2438,7 +2536,7 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
     REQUIRE(blocks <= 2147483647u, "grid too large");
     const double* acoef = series;
     if (!acoef) {      // the caller did not bring the series rows (hmg_halo_stage): build them here
-        if (ensure_scratch(c, 5, (size_t)nz * nm * NFW_NS2 * 8)) return 1;
+        if (ensure_scratch(c, 5, (size_t)nz * nm * NFW_ROW * 8)) return 1;
         acoef = (const double*)c->scratch[5];
         hipLaunchKernelGGL(nfw_series_kernel, grid1d((size_t)nz * nm, 128), dim3(128), 0, c->stream, nz * nm, cs,
                            (double*)c->scratch[5]);
@@ -2574,7 +2672,8 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
                     const double* amp, const double* xcs, const double* alpha, const double* expo,
                     double amp_c, double xc_c, double alpha_c, double expo_c, double gamma,
                     const double* cmax, const double* rss, const double* zs, const double* ks,
-                    int do_mass_norm, const double* post, double* out, int* nconst, double* cconst) {
+                    int do_mass_norm, const double* post, double* out, int* nconst, double* cconst,
+                    const double* logxs) {
     REQUIRE(c && xs && kts && cmax && rss && zs && ks && out, "NULL argument");
     REQUIRE((nconst == nullptr) == (cconst == nullptr), "pass both hint arrays or neither");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
@@ -2594,10 +2693,10 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
             A.amp_c = amp_c; A.xc_c = xc_c; A.alpha_c = alpha_c; A.expo_c = expo_c; A.gamma = gamma;
             A.step = step; A.cmax = cmax; A.rss = rss; A.zs = zs; A.ks = ks; A.post = post; A.out = out;
             A.nconst = nconst; A.cconst = cconst;
-            A.logx = nullptr;
+            A.logx = logxs;
             int stop = -1;
             if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
-            if (rows >= 8192) {      // enough rows for the table's own launch to pay (MI355X: -1 % at 16384 rows, +2 % at 4096)
+            if (!logxs && rows >= 8192) {   // no prepared table: its own launch pays from ~8000 rows (MI355X: -1 % at 16384 rows, +2 % at 4096)
                 if (ensure_scratch(c, 2, (size_t)nxs * 8)) return 1;
                 hipLaunchKernelGGL(logx_kernel, grid1d((size_t)nxs, 256), dim3(256), 0, c->stream, nxs, xs,
                                    (double*)c->scratch[2]);
@@ -2651,6 +2750,13 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
         HIP_TRY(hipGetLastError());
     }
     return bracket_close(c, stop);
+}
+
+int hmg_profile_fft_logx(hmg_ctx* c, int nxs, const double* xs, double* logxs) {
+    REQUIRE(c && xs && logxs && nxs > 0, "bad argument");
+    hipLaunchKernelGGL(logx_kernel, grid1d((size_t)nxs, 256), dim3(256), 0, c->stream, nxs, xs, logxs);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int hmg_hod(hmg_ctx* c, int nz, int nm, const hmg_hod_params* p, const double* zs, const double* ms,

@@ -355,9 +355,7 @@ class HaloModel(Cosmology):
         self._sync_point()               # start of a pass: everything launched so far precedes it
         ctx = self._aux()
         self._d_sigma2 = self._buf("sigma2", (nz, nm))
-        ctx.call("hmg_sigma2_prepared", nz, nm, d_kq.size, d_PT.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
-                 float(self.p["Wkr_taylor_switch"]), self._d_sigma2.ptr)
-        # n(z,m), b(z,m)
+        # n(z,m), b(z,m): same launch as the second stage of the sigma^2 contraction
         if "mf_in" not in self._dcache:
             lnm = np.log(ms)
             uniform, step = gradient_is_uniform(lnm)
@@ -368,17 +366,20 @@ class HaloModel(Cosmology):
             d_tz = ctx.upload(self._tinker_z_params()) if self.mode == "tinker" else None
             delta, rho = self._mdef_delta_rho()
             self._dcache["mf_in"] = (par, ctx.upload(lnm), d_tz, ctx.upload(delta), ctx.upload(rho))
+            ctx = self._aux()            # (the uploads above synchronise on whatever lane is current)
         par, d_lnm, d_tz, d_delta, d_rho = self._dcache["mf_in"]
         self._d_nzm, self._d_bh = self._buf("nzm", (nz, nm)), self._buf("bh", (nz, nm))
-        ctx.call("hmg_massfn", nz, nm, C.byref(par), self._d_sigma2.ptr, self._d_ms().ptr, d_lnm.ptr,
-                 nat.ptr(d_tz), self._d_nzm.ptr, self._d_bh.ptr)
+        d_ms = self._d_ms()
+        ctx.call("hmg_sigma2_massfn", nz, nm, d_kq.size, d_PT.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
+                 float(self.p["Wkr_taylor_switch"]), C.byref(par), d_ms.ptr, d_lnm.ptr, nat.ptr(d_tz),
+                 self._d_sigma2.ptr, self._d_nzm.ptr, self._d_bh.ptr)
         self._aux_done()
         # c(z,m), rvir(z,m), rs(z,m): independent of sigma2 -> main lane, ahead of the profile kernels
         sfx = self.mdef
         self._d_cs, self._d_rvir, self._d_rs = (self._buf(k, (nz, nm)) for k in ("cs", "rvir", "rs"))
         # ... together with the series rows of the analytic NFW kernel and the vir -> 200c mass
         # conversion the Battaglia profiles need (all one thread per (z,m): one launch)
-        self._d_nfw_series = self._buf("nfw_series", (nz, nm, 32))
+        self._d_nfw_series = self._buf("nfw_series", (nz, nm, nat.NFW_SERIES_STRIDE))
         m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
         d_drho1 = self._d_drho1()
         d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
@@ -445,7 +446,10 @@ class HaloModel(Cosmology):
             step = (xs[-1] - xs[0]) / xs.size
             kts = np.fft.rfftfreq(xs.size, step) * 2 * np.pi
             ctx = self._ctx()
-            self._dcache[key] = (ctx.upload(xs), ctx.upload(kts), float(step))
+            d_xs = ctx.upload(xs)
+            d_lx = ctx.empty((xs.size,))            # ln x_n, shared by every row of every pass
+            ctx.call("hmg_profile_fft_logx", xs.size, d_xs.ptr, d_lx.ptr)
+            self._dcache[key] = (d_xs, ctx.upload(kts), float(step), d_lx)
         return self._dcache[key]
 
     def _profile_fft(self, key, nxs, xmax, rowp, consts, gamma, d_cmax, d_rss, do_mass_norm, d_post=None):
@@ -455,7 +459,7 @@ class HaloModel(Cosmology):
         is only requested when the target k grid is ascending."""
         ctx = self._ctx()
         nz, nm, nk = self._nz, self._nm, self._nk
-        d_xs, d_kts, step = self._fft_grids(xmax, nxs)
+        d_xs, d_kts, step, d_lx = self._fft_grids(xmax, nxs)
         out = self._buf(key, (nz, nm, nk))
         if "ks_ascending" not in self._dcache:
             self._dcache["ks_ascending"] = (bool(np.all(np.diff(self.ks) > 0))
@@ -469,7 +473,8 @@ class HaloModel(Cosmology):
                  nat.ptr(amp), nat.ptr(xc), nat.ptr(alpha), nat.ptr(expo),
                  float(consts[0]), float(consts[1]), float(consts[2]), float(consts[3]), float(gamma),
                  d_cmax.ptr, d_rss.ptr, self._d_zs().ptr, self._d_ks().ptr, int(do_mass_norm),
-                 nat.ptr(d_post), out.ptr, nat.ptr(hint[0] if hint else None), nat.ptr(hint[1] if hint else None))
+                 nat.ptr(d_post), out.ptr, nat.ptr(hint[0] if hint else None), nat.ptr(hint[1] if hint else None),
+                 d_lx.ptr)
         return out, hint
 
     def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref):

@@ -123,6 +123,13 @@ int hmg_massfn(hmg_ctx* ctx, int nz, int nm, const hmg_massfn_params* h_par,
                const double* d_tinker_z /*[nz][5] = alpha,beta,phi,eta,gamma at clamped z; NULL for ST*/,
                double* d_nzm /*[nz][nm]*/, double* d_bh /*[nz][nm]*/);
 
+/* hmg_sigma2_prepared + hmg_massfn with the second stage of the contraction (the ordered sum over the
+ * k' segments) folded into the mass-function launch: two launches instead of three, same sigma2 bits. */
+int hmg_sigma2_massfn(hmg_ctx* ctx, int nz, int nm, int nq, const double* d_PT,
+                      const double* d_kq, const double* d_wq, const double* d_R, double taylor_switch,
+                      const hmg_massfn_params* h_par, const double* d_ms, const double* d_lnms,
+                      const double* d_tinker_z, double* d_sigma2, double* d_nzm, double* d_bh);
+
 /* ---- A5: concentration, virial radius, scale radius -----------------------------------
  * Replaces duffy_concentration / concentration / rvir (hmvec/hmvec.py:68-73,111-115,163-176).
  *   c = A (h m / 2e12)^alpha (1+z)^beta ;  rvir = (3 m / (4 pi delta[z] rho[z]))^(1/3) ;
@@ -135,9 +142,11 @@ int hmg_halo_structure(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const d
 
 /* hmg_halo_structure, the series rows of the analytic NFW kernel and hmg_mdelta_convert in ONE launch
  * (they are all one-thread-per-(z,m) stages that precede the profile kernels of a pass):
- *   d_nfw_series [nz][nm][32] (or NULL): per-row coefficients of u_NFW's small-argument series, to be
- *     handed to hmg_nfw_analytic, which otherwise computes them with a launch of its own;
+ *   d_nfw_series [nz][nm][HMG_NFW_SERIES_STRIDE] (or NULL): per-row coefficients of u_NFW's
+ *     small-argument series and the row constants of its closed forms, to be handed to
+ *     hmg_nfw_analytic, which otherwise computes them with a launch of its own;
  *   d_m2, d_r2 (both or NULL): the mass conversion of hmg_mdelta_convert with d_drho1, delta2, d_rho2.  */
+#define HMG_NFW_SERIES_STRIDE 36
 int hmg_halo_stage(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const double* d_zs,
                    const double* d_delta /*[nz]*/, const double* d_rho /*[nz]*/,
                    double duffy_A, double duffy_alpha, double duffy_beta, double h,
@@ -214,7 +223,12 @@ int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_st
                     const double* d_zs, const double* d_ks, int do_mass_norm,
                     const double* d_post /*[nz][nm] or NULL*/,
                     double* d_out /*[nz][nm][nk]*/,
-                    int* d_nconst /*[nz][nm] or NULL*/, double* d_cconst /*[nz][nm] or NULL*/);
+                    int* d_nconst /*[nz][nm] or NULL*/, double* d_cconst /*[nz][nm] or NULL*/,
+                    const double* d_logxs /*[nxs] from hmg_profile_fft_logx for the SAME d_xs, or NULL*/);
+/* ln xs[n]: the same for every (z,m) row, so a caller whose x grid does not change between passes
+ * computes it once and hands it to hmg_profile_fft (one transcendental fewer per sample; without it
+ * the kernel evaluates the logarithm itself, or builds the table per call when there are many rows). */
+int hmg_profile_fft_logx(hmg_ctx* ctx, int nxs, const double* d_xs, double* d_logxs);
 /* d_nconst / d_cconst (both or neither): constant-prefix hint of every output row for hmg_tracer -
  * the number of leading target wavenumbers below the row's first FFT mode and the value they all
  * receive.  Only meaningful when d_ks is ascending (the caller's responsibility).               */
