@@ -575,8 +575,9 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* 
                                                   const double* __restrict__ zs,
                                                   const double* __restrict__ ks,
                                                   double* __restrict__ uk) {
-    // one wavefront per workgroup: rows x k-tiles of work items keep all SIMDs busy even for a
-    // thin z-slab, and the grid quantises finely (the row constants cost ~1 % per tile)
+    // one (z,m) row per workgroup, the whole k axis in one tile: measured against two rows per workgroup
+    // (+4 %), half tiles (+40 %) and 128 threads per row (+-0): a workgroup's fixed cost is the latency of
+    // its scalar loads (row constants, series coefficients), not instructions
     const int ktiles = (nk + ktile - 1) / ktile;
     const int row = blockIdx.x / ktiles;  // z*nm + m
     const int k_lo = (blockIdx.x - row * ktiles) * ktile;
@@ -998,21 +999,32 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
     const double EX = A.expo ? A.expo[row] : A.expo_c;
     const double cm = A.cmax[row];
-    const double ln_xc = log_fast(XC);          // ln(x/xc) = ln x - ln xc: ln x is row-independent
+    // ln(x/xc) = ln x - ln xc: ln x is row-independent (xc == 1 for the gas and NFW members: no logarithm)
+    const double ln_xc = (A.xc == nullptr && A.xc_c == 1.0) ? 0.0 : log_fast(XC);
     // Output side of the row: the FFT modes sit on the uniform grid kout_j = j k_lo,
     // k_lo = kt_1 / (r_s (1+z)).  Targets below k_lo take np.interp's left fill u_1, targets above
     // kout_M are zero, and only the modes j <= jn = floor(max(ks)/k_lo) + 2 can be reached at all:
     // low-mass rows (large k_lo) need a few dozen of the M modes, so the unpack and the last FFT
     // pass are cut down to those.  max(ks) is only known without a search when ks is ascending,
     // which is the caller's promise that comes with the hint arrays (include/hmgrid.h).
+    // These row scalars are the same for all 512 threads and cost a few divisions: thread 0 works them out
+    // while the others start on the integrand, and they travel through LDS behind the barriers that
+    // are there anyway (red[17..23]: left-fill counter, jn, 1/(r_s(1+z)), k_lo, k_hi, 1/k_lo, u scale).
     const int z = row / A.nm;
-    int jn = M;
-    if (A.nconst) {
-        const double tmax = A.ks[A.nk - 1] * (A.rss[row] * (1.0 + A.zs[z])) / A.kts[1];
-        if (tmax < (double)(M - 4)) jn = (int)tmax + 3;    // one spare mode for the rounding of tmax
+    int* s_jn = reinterpret_cast<int*>(red + 18);
+    if (threadIdx.x == 0) {
+        *s_cnt = 0;
+        const double isc0 = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));      // kout_j = kts[j] * isc
+        const double klo0 = A.kts[1] * isc0;
+        const double idk0 = 1.0 / klo0;
+        int jn0 = M;
+        if (A.nconst) {
+            const double tmax = A.ks[A.nk - 1] * idk0;
+            if (tmax < (double)(M - 4)) jn0 = (int)tmax + 3;           // one spare mode for the rounding of tmax
+        }
+        *s_jn = jn0;
+        red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
     }
-    jn = __builtin_amdgcn_readfirstlane(jn);
-    if (threadIdx.x == 0) *s_cnt = 0;
     // ---- phase A: y_n = x_n rho(x_n) theta(x_n <= cmax) packed as (y_2p, y_2p+1); mass norm
     // Pruned first pass: the integrand is zero beyond the truncation radius (85 % of a Battaglia
     // row at xmax = 20).  When every packed sample p >= M/R0 is zero, the first radix-R0 pass
@@ -1042,9 +1054,13 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     }
     {
         const double tot = block_sum(acc, red);   // contains the barrier that publishes buf
-        if (threadIdx.x == 0) s_mn = A.do_norm ? tot : 1.0;
+        if (threadIdx.x == 0) {
+            s_mn = A.do_norm ? tot : 1.0;
+            red[23] = -A.step / s_mn;             // u_j = Im F_j * this / kt_j
+        }
     }
     __syncthreads();
+    const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
 #if defined(HMG_ABL) && HMG_ABL == 1     // timing experiments only: stop after phase A
     if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + s_mn;
     return;
@@ -1071,8 +1087,7 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
 #endif
     // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm for the reachable modes
     // j = 1..jn, into smem[0..jn-1]
-    const double inv_mn = 1.0 / s_mn;
-    const double sc = -A.step * inv_mn;
+    const double sc = red[23];
     double ua[MAXP], ub[MAXP];
     const int half = M / 2;
 #pragma unroll
@@ -1108,9 +1123,7 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid:
     // bracket j = floor(k/k_lo), weight k/k_lo - j (one FMA), two LDS reads.  The left fill is a
     // plain splat (63 % of the Battaglia tensor at Config 3).
-    const double isc = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));  // kout_j = kts[j] * isc
-    const double k_lo = A.kts[1] * isc, k_hi = A.kts[M] * isc;
-    const double inv_dk = 1.0 / k_lo;
+    const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
     const double pf = A.post ? A.post[row] : 1.0;
     const double u1 = u[0];
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
@@ -2525,9 +2538,7 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
     // 16 k per thread amortise the per-row prologue (a log, two divisions, the scalar loads of the
     // series row); smaller tiles were measured slower at every grid size once the series made the
     // per-point cost small
-    // 128 threads per row once there are enough rows to fill the chip several times over (32 k per thread
-    // amortise the row set-up better: -4 % at 16384 rows, +6 % at 4096)
-    int threads = (size_t)nz * nm >= 12288 ? 128 : 256, ktile = 4096;
+    int threads = 256, ktile = 4096;
     if (const char* e = getenv("HMG_NFW_THREADS")) threads = atoi(e);
     if (const char* e = getenv("HMG_NFW_KTILE")) ktile = atoi(e);
     REQUIRE(threads == 64 || threads == 128 || threads == 256, "HMG_NFW_THREADS must be 64/128/256");
