@@ -982,7 +982,10 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
 #ifndef HMG_FUSED_OCC
 #define HMG_FUSED_OCC 8
 #endif
-template <int NT, int MAXB, int MAXP>
+// SPECM != 0: the plan is known at compile time (SPECM = 2500, passes 4,5,5,5,5: nxs = 5000, the default
+// length of the Battaglia profiles) - strides, twiddle steps and the j/Ns multipliers become immediates and
+// the pass loop with its dispatch chain unrolls.
+template <int NT, int MAXB, int MAXP, int SPECM>
 __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_fused_kernel(FusedArgs A) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     extern __shared__ __attribute__((aligned(16))) double smem[];
     cplx* buf = reinterpret_cast<cplx*>(smem);
     const int row = blockIdx.x;
-    const int M = A.plan.M, nxs = A.nxs;
+    const int M = SPECM ? SPECM : A.plan.M, nxs = SPECM ? 2 * SPECM : A.nxs;
     double* red = smem + 2 * (size_t)M;
     double& s_mn = red[16];
     int* s_cnt = reinterpret_cast<int*>(red + 17);
@@ -1031,9 +1034,9 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     // sees (v0, 0, ..., 0) in every butterfly, whose DFT is v0 in all R0 outputs - exactly, in
     // floating point - so phase A writes each sample straight into its R0 output slots and the
     // pass (an LDS round trip, two barriers, the zero fill of the rest of the row) is skipped.
-    const int R0 = A.plan.radix[0];
+    const int R0 = SPECM ? 4 : A.plan.radix[0];
     const int stride0 = M / R0;
-    const bool pruned = A.plan.npass > 1 && A.xs[2 * stride0] > cm;   // xs is increasing
+    const bool pruned = (SPECM || A.plan.npass > 1) && A.xs[2 * stride0] > cm;   // xs is increasing
     double acc = 0.0;
     for (int p = threadIdx.x; p < (pruned ? stride0 : M); p += NT) {
         const int j = 2 * p;
@@ -1069,6 +1072,15 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     // (Tried and dropped, MI355X: fetching all R operands before the twiddle products and requesting the
     // next pass's twiddle between the two halves of a pass.  Both lengthen live ranges under the 64-VGPR
     // cap of 8 waves/SIMD: 0.277 -> 0.315 ms.)
+    if constexpr (SPECM == 2500) {
+        constexpr unsigned mg4 = 4294967296ull / 4 + 1, mg20 = 4294967296ull / 20 + 1, mg100 = 4294967296ull / 100 + 1,
+                           mg500 = 4294967296ull / 500 + 1;
+        if (!pruned) fused_pass<NT, 4, MAXB>(buf, A.twM, 2500, 1, 625, 0u, -1);
+        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 4, 125, mg4, -1);
+        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 20, 25, mg20, -1);
+        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 100, 5, mg100, -1);
+        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
+    } else
     for (int ps = pruned ? 1 : 0; ps < A.plan.npass; ++ps) {
         const int R = A.plan.radix[ps], Ns = A.plan.ns[ps], tws = A.plan.twstep[ps];
         const unsigned mg = A.plan.magic[ps];
@@ -2667,13 +2679,13 @@ static int get_fused_plan(hmg_ctx* c, int nxs, FusedPlan** out) {
     return 0;
 }
 
-template <int MAXB, int MAXP>
+template <int MAXB, int MAXP, int SPECM = 0>
 static int launch_fused(hmg_ctx* c, const FusedArgs& A, int rows) {
     const size_t lds = (size_t)A.plan.M * 16 + 32 * sizeof(double);
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)profile_fused_kernel<FUSED_NT, MAXB, MAXP>,
+        HIP_TRY(hipFuncSetAttribute((const void*)profile_fused_kernel<FUSED_NT, MAXB, MAXP, SPECM>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((profile_fused_kernel<FUSED_NT, MAXB, MAXP>), dim3(rows), dim3(FUSED_NT), lds,
+    hipLaunchKernelGGL((profile_fused_kernel<FUSED_NT, MAXB, MAXP, SPECM>), dim3(rows), dim3(FUSED_NT), lds,
                        c->stream, A);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2716,8 +2728,13 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
             }
             int rc;
             const int mb = FP->maxb, mp = FP->maxp;
-            if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
-            else if (mb <= 2 && mp <= 3) rc = launch_fused<2, 3>(c, A, rows);   // nxs = 5000
+            const FftPlanDev& pl = FP->plan;
+            const bool spec2500 = FUSED_NT == 512 && pl.M == 2500 && pl.npass == 5 && pl.radix[0] == 4 && pl.radix[1] == 5 &&
+                                  pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
+                                  !getenv("HMG_FUSED_GENERIC");      // (testing: force the run-time plan)
+            if (spec2500) rc = launch_fused<2, 3, 2500>(c, A, rows);                 // nxs = 5000, compile-time plan
+            else if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
+            else if (mb <= 2 && mp <= 3) rc = launch_fused<2, 3>(c, A, rows);
             else if (mb <= 2 && mp <= 4) rc = launch_fused<2, 4>(c, A, rows);
             else rc = launch_fused<4, 8>(c, A, rows);
             if (rc) return 1;

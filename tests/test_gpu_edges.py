@@ -350,3 +350,27 @@ def test_mass_integral_launch_shapes_agree_bit_for_bit(monkeypatch, nm):
     for (a, b), p1, p2 in zip(pairs, out["0"][:6], out["0"][6:]):
         ok, w = power_close(p1 + p2, o.get_power(a, b))
         assert ok, (a, b, w)
+
+
+def test_compile_time_plan_equals_run_time_plan(monkeypatch):
+    """nxs = 5000 (the Battaglia default) runs a build of the fused profile kernel whose FFT plan is a
+    compile-time constant; the run-time-plan build of the same kernel must give the same bits, for rows
+    that take the pruned first pass and rows that do not (xmax small enough that cmax > xmax/4)."""
+    import hmvec_amd as hm
+    zs = np.array([0.2, 1.1, 2.7])
+    ms = np.geomspace(2e10, 1e17, 40)
+    ks = np.geomspace(1e-4, 100, 300)
+    out = {}
+    for generic in ("0", "1"):
+        if generic == "1":
+            monkeypatch.setenv("HMG_FUSED_GENERIC", "1")
+        h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+        h.add_battaglia_profile("e20", nxs=5000, xmax=20)          # truncation at ~2.6 of 20: first pass pruned
+        h.add_battaglia_profile("e8", nxs=5000, xmax=8)            # 2.6 > 8/4: not pruned
+        h.add_battaglia_pres_profile("y", nxs=5000, xmax=20)
+        out[generic] = (h.uk_profiles["e20"].copy(), h.uk_profiles["e8"].copy(), h.pk_profiles["y"].copy())
+    monkeypatch.delenv("HMG_FUSED_GENERIC")
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+    o = oracle_for(h, zs, ks, ms, 5000, 8)
+    assert np.max(np.abs(out["0"][1] - o.uk_profiles["electron"])) < 1e-12
