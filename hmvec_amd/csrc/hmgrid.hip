@@ -220,8 +220,12 @@ __global__ void transpose_pad_kernel(int rows, int rows_pad, int cols, const dou
     out[i] = r < rows ? in[(size_t)r * cols + c] : 0.0;
 }
 
+// (132 VGPRs, 3 waves/SIMD; forcing 4 spills and is no faster: 23.5 vs 24.0 us at Config 3)
+#ifndef HMG_SIG_OCC
+#define HMG_SIG_OCC 1
+#endif
 template <int ZB>
-__global__ __launch_bounds__(64) void sigma2_mfma_kernel(int nz, int nzp, int nm, int nq,
+__global__ __launch_bounds__(64, HMG_SIG_OCC) void sigma2_mfma_kernel(int nz, int nzp, int nm, int nq,
                                                          const double* __restrict__ PT /*[nq][nzp]*/,
                                                          const double* __restrict__ kq,
                                                          const double* __restrict__ wq,
@@ -237,32 +241,32 @@ __global__ __launch_bounds__(64) void sigma2_mfma_kernel(int nz, int nzp, int nm
     for (int b = 0; b < ZB; ++b) acc[b] = d4_t{0.0, 0.0, 0.0, 0.0};
     const int q_lo = seg * SIG_SEG_LEN, q_hi = min(nq, q_lo + SIG_SEG_LEN);
     constexpr int NT = SIG_SEG_LEN / 16;      // trips of four MFMA k-steps
-    // Phase 1: every load of the segment - k', quadrature weight and the P rows - is issued up front
-    // (positions past the end of the segment are clamped and given zero weight), so the wave pays
-    // one memory latency instead of one per trip.
-    double kv[NT][4], wv[NT][4], pv[NT][4][ZB];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
+    // Two-stage pipeline over the trips: the loads of trip t+1 (k', quadrature weight, the P rows; positions
+    // past the end of the segment are clamped and given zero weight) are issued before trip t's window
+    // values are evaluated, so a wavefront holds two trips of operands instead of the whole segment
+    // (236 -> ~120 VGPRs: four wavefronts per SIMD instead of two, which is what feeds the VALU here).
+    // The MFMA accumulation order over k' is unchanged.
+    struct Trip { double kv[4], wv[4], pv[4][ZB]; };
+    auto load_trip = [&](Trip& T, int t) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = q_lo + 16 * t + 4 * u + kk;
             const int qc = min(q, nq - 1);
-            kv[t][u] = kq[qc];
+            T.kv[u] = kq[qc];
             const double w = wq[qc];
-            wv[t][u] = (q < q_hi) ? w : 0.0;
+            T.wv[u] = (q < q_hi) ? w : 0.0;
             const double* __restrict__ prow = PT + (size_t)qc * nzp + z0 + col;
 #pragma unroll
-            for (int b = 0; b < ZB; ++b) pv[t][u][b] = prow[16 * b];
+            for (int b = 0; b < ZB; ++b) T.pv[u][b] = prow[16 * b];
         }
-    // Phase 2: window values (branch-free: Taylor and trigonometric forms both evaluated, selected by
-    // kR; the library sincos is only called if some lane has kR >= 1e9) and the MFMA accumulation
-    // in the same k' order as before.
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    };
+    // window values (branch-free: Taylor and trigonometric forms both evaluated, selected by kR; the library
+    // sincos is only called if some lane has kR >= 1e9) and the MFMA accumulation
+    auto consume = [&](const Trip& T) {
         double a[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const double kR = kv[t][u] * r;
+            const double kR = T.kv[u] * r;
             const double xx = kR * kR;
             const double wt = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
             double sn, cs;
@@ -272,13 +276,22 @@ __global__ __launch_bounds__(64) void sigma2_mfma_kernel(int nz, int nzp, int nm
             }
             const double wtr = 3.0 * (sn - kR * cs) * rcp_fast(fmax(xx * kR, 1.0e-300));
             const double w = (kR < tswitch) ? wt : wtr;
-            a[u] = wv[t][u] * (w * w);
+            a[u] = T.wv[u] * (w * w);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int b = 0; b < ZB; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[t][u][b], a[u], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(T.pv[u][b], a[u], acc[b], 0, 0, 0);
+    };
+    Trip ta, tb;
+    load_trip(ta, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t += 2) {
+        if (t + 1 < NT) load_trip(tb, t + 1);
+        consume(ta);
+        if (t + 2 < NT) load_trip(ta, t + 2);
+        if (t + 1 < NT) consume(tb);
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
     if (m < nm) {
