@@ -437,6 +437,26 @@ class Cosmology(object):
         return None
 
 
+_UPLOAD_CACHE_MAX = 64
+
+
+def _cached_upload(ctx, arr):
+    """Device copy of a small host array, reused while the same bytes are asked for again (per context,
+    least-recently-used, at most _UPLOAD_CACHE_MAX entries of <= 1 MB)."""
+    a = np.ascontiguousarray(arr, dtype=np.float64)
+    if a.nbytes > (1 << 20):
+        return ctx.upload(a)
+    cache = ctx.__dict__.setdefault("_small_uploads", {})
+    key = (a.shape, hash(a.tobytes()))
+    hit = cache.pop(key, None)
+    if hit is None or not np.array_equal(hit[0], a):
+        hit = (a.copy(), ctx.upload(a))
+    cache[key] = hit                      # most recently used last
+    while len(cache) > _UPLOAD_CACHE_MAX:
+        cache.pop(next(iter(cache)))
+    return hit[1]
+
+
 def _limber(ctx, ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis):
     ells = np.ascontiguousarray(ells, dtype=np.float64)
     zs = np.atleast_1d(np.asarray(zs, dtype=np.float64))
@@ -457,7 +477,9 @@ def _limber(ctx, ells, zs, ks, Pzks, gzs, Wz1s, Wz2s, hzs, chis):
         dP, dP2 = Pzks
     else:
         dP = Pzks if isinstance(Pzks, nat.DeviceArray) else ctx.upload(np.asarray(Pzks, dtype=np.float64))
-    d = [ctx.upload(a) for a in (ells, zs, ks, gzs, pref, chis + 0.0 * gzs, wz)]
+    # small inputs (multipoles, grids, window products) are kept on the device between calls: a Limber
+    # projection of device-resident spectra then costs one launch and one small copy back
+    d = [_cached_upload(ctx, a) for a in (ells, zs, ks, gzs, pref, chis + 0.0 * gzs, wz)]
     out = ctx.empty((ells.size,))
     ctx.call("hmg_limber", ells.size, d[0].ptr, zs.size, ks.size, d[1].ptr, d[2].ptr, dP.ptr, nat.ptr(dP2),
              gzs.size, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr, out.ptr)

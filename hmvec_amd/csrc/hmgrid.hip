@@ -1055,8 +1055,13 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
         const int j = 2 * p;
         const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
         double r0 = 0.0, r1 = 0.0;
+#if defined(HMG_ABL) && HMG_ABL == 4     // timing experiment: phase A without its transcendentals
+        if (!(fabs(xv.x) > cm)) r0 = Aamp * xv.x + AL;
+        if (!(fabs(xv.y) > cm)) r1 = Aamp * xv.y + EX;
+#else
         if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
         if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+#endif
         const cplx y = cplx{xv.x * r0, xv.y * r1};
         if (pruned) {
             for (int t = 0; t < R0; ++t) buf[R0 * p + t] = y;
@@ -1077,7 +1082,7 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     }
     __syncthreads();
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
-#if defined(HMG_ABL) && HMG_ABL == 1     // timing experiments only: stop after phase A
+#if defined(HMG_ABL) && (HMG_ABL == 1 || HMG_ABL == 4)     // timing experiments only: stop after phase A
     if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + s_mn;
     return;
 #endif
@@ -2698,6 +2703,9 @@ static int launch_fused(hmg_ctx* c, const FusedArgs& A, int rows) {
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)profile_fused_kernel<FUSED_NT, MAXB, MAXP, SPECM>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (Tried and dropped: fewer workgroups that loop over rows, to take the ~4 us of workgroup launch and
+    // first-load latency per row off the path.  The loop-carried state spills under the 64-VGPR cap:
+    // 0.21 -> 0.56-0.61 ms, with 1023, 2047 or one workgroup per row alike.)
     hipLaunchKernelGGL((profile_fused_kernel<FUSED_NT, MAXB, MAXP, SPECM>), dim3(rows), dim3(FUSED_NT), lds,
                        c->stream, A);
     HIP_TRY(hipGetLastError());
@@ -2808,7 +2816,10 @@ int hmg_hod(hmg_ctx* c, int nz, int nm, const hmg_hod_params* p, const double* z
     REQUIRE(nz > 0 && nm > 0, "empty grid");
     REQUIRE(p->corr == 0 || p->corr == 1, "corr must be 0 (max) or 1 (min)");
     HodDev P{p->sig_log_mstellar, p->alphasat, p->Bsat, p->betasat, p->Bcut, p->betacut, p->corr};
-    hipLaunchKernelGGL(hod_kernel, dim3(nz), dim3(1024), 0, c->stream, nm, P, zs, ms, lthr, nzm, bh, wm,
+    int hod_threads = 1024;
+    if (const char* e = getenv("HMG_HOD_THREADS")) hod_threads = atoi(e);
+    REQUIRE(hod_threads >= 64 && hod_threads <= 1024 && hod_threads % 64 == 0, "HMG_HOD_THREADS must be a multiple of 64 up to 1024");
+    hipLaunchKernelGGL(hod_kernel, dim3(nz), dim3(hod_threads), 0, c->stream, nm, P, zs, ms, lthr, nzm, bh, wm,
                        Nc, Ns, NsNsm1, NcNs, ngal, bg);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Phase ablation of the fused profile kernel (timing only; results of the ablated builds are garbage):
 # libhmgrid_abl{1,2,3}.so stop after phase A / B / C (make OUT=../libhmgrid_ablN.so EXTRA=-DHMG_ABL=N).
-for v in abl1 abl2 abl3 full; do
+for v in ${ABLS:-abl1 abl2 abl3 full}; do
   if [ $v = full ]; then unset HMG_LIB_PATH; else export HMG_LIB_PATH=$PWD/hmvec_amd/libhmgrid_$v.so; fi
   python bench.py --no-cpu-baseline --no-limber --steps 40 "$@" > /tmp/abl_$v.json 2>/tmp/abl_$v.err || { tail -3 /tmp/abl_$v.err; continue; }
   python - $v <<'PY'
