@@ -418,7 +418,7 @@ def main():
         return None
 
     hint_n = h.uk_profiles.hint("electron")[0]
-    vec = 2 if nk_ % 2 == 0 and (nk_ + 127) // 128 * nzl >= 256 else 1
+    vec = 2 if nk_ % 2 == 0 and (nk_ + 127) // 128 * nzl >= 256 else 1      # hmg_power_batch's tile rule (256 CUs)
     if hint_n is not None and not args.per_pair:
         nconst = hint_n.numpy().view(np.int32)[:B]
         pw_model, pw_tens = power_bytes_moved(nzl, nm_, nk_, npair, nconst, vec)

@@ -3005,10 +3005,17 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     // thin z-slabs: narrower k tiles so that every CU still gets a workgroup, and sixteen wavefronts per
     // workgroup (one per virtual mass slice) so that each CU keeps twice the loads in flight.  The
     // summation order is the same in both shapes (see power_batch_kernel).
-    int thin = (long)((nk + 127) / 128) * nz < c->num_cu ? 1 : 0;
+    // Shapes by the number of 128-k tiles the launch offers the chip (measured, MI355X, nm = 512, nk = 4096):
+    // fewer than one per CU (nz = 4): 64-k tiles, 16 wavefronts (0.035 ms; 128-k tiles 0.039);
+    // one to two per CU (nz = 8): 128-k tiles, 16 wavefronts (0.046 ms; 8 wavefronts 0.055);
+    // more: 128-k tiles, 8 wavefronts, two workgroups per CU (16 wavefronts: +2 %).
+    const long tiles128 = (long)((nk + 127) / 128) * nz;
+    int thin = tiles128 < c->num_cu ? 1 : (tiles128 < 2L * c->num_cu && vec2 ? 3 : 0);
     if (const char* e = getenv("HMG_PB_THIN")) thin = atoi(e);      // tuning/testing: force a shape (2: V=1, 8 wavefronts)
-    if (thin) vec2 = false;
+    if (thin == 3 && !vec2) thin = 1;
+    if (thin == 1 || thin == 2) vec2 = false;
 #define PB_V(NT_, NTR_)                                                              \
+    if (thin == 3) return launch_power_batch<NT_, NTR_, 2, true>(c, A, nz);          \
     return thin == 1 ? launch_power_batch<NT_, NTR_, 1, true>(c, A, nz)              \
                      : (vec2 ? launch_power_batch<NT_, NTR_, 2, false>(c, A, nz)     \
                              : launch_power_batch<NT_, NTR_, 1, false>(c, A, nz));

@@ -339,12 +339,12 @@ def test_mass_integral_launch_shapes_agree_bit_for_bit(monkeypatch, nm):
     h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
     pairs = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("nfw", "electron"), ("g", "nfw"), ("g", "electron")]
     out = {}
-    for thin in ("0", "1"):
+    for thin in ("0", "1", "3"):
         monkeypatch.setenv("HMG_PB_THIN", thin)
         o1, o2 = h.power_device_batch(pairs)
         out[thin] = [a.numpy() for a in o1] + [a.numpy() for a in o2]
-    for a, b in zip(out["0"], out["1"]):
-        assert np.array_equal(a, b)
+    for a, b, c3 in zip(out["0"], out["1"], out["3"]):
+        assert np.array_equal(a, b) and np.array_equal(a, c3)
     monkeypatch.delenv("HMG_PB_THIN")
     o = oracle_for(h, zs, ks, ms, 300, 20)
     for (a, b), p1, p2 in zip(pairs, out["0"][:6], out["0"][6:]):
