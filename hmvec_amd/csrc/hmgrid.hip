@@ -1010,6 +1010,10 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     double* red = smem + 2 * (size_t)M;
     double& s_mn = red[16];
     int* s_cnt = reinterpret_cast<int*>(red + 17);
+#if defined(HMG_ABL) && HMG_ABL == 5     // timing experiment: workgroup launch only
+    if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = 1.0;
+    return;
+#endif
     const double Aamp = A.amp ? A.amp[row] : A.amp_c;
     const double XC = A.xc ? A.xc[row] : A.xc_c;
     const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
@@ -1041,6 +1045,10 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
         *s_jn = jn0;
         red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
     }
+#if defined(HMG_ABL) && HMG_ABL == 6     // timing experiment: launch + row scalars, no integrand
+    if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = Aamp + XC + AL + EX + cm + ln_xc;
+    return;
+#endif
     // ---- phase A: y_n = x_n rho(x_n) theta(x_n <= cmax) packed as (y_2p, y_2p+1); mass norm
     // Pruned first pass: the integrand is zero beyond the truncation radius (85 % of a Battaglia
     // row at xmax = 20).  When every packed sample p >= M/R0 is zero, the first radix-R0 pass
