@@ -252,6 +252,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if os.environ.get("HMG_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0       # functional rehearsal of the N > 1 path on a one-GPU box (timings meaningless)
     args.gpus = world
     # Multi-process GPU work on this platform needs dmabuf IPC (the task environment exports it; keep it
     # if a launcher dropped it).  Set here, in the benchmark, before anything loads the HIP runtime -
