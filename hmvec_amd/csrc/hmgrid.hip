@@ -153,10 +153,26 @@ namespace hmg {
 
 constexpr int WAVE = 64;
 
+// Sum over the 64 lanes of a wavefront, returned in EVERY lane.  Cross-lane moves are DPP modifiers
+// (register-to-register, a few cycles) instead of __shfl (ds_bpermute: an LDS-pipeline round trip per
+// step, twelve dependent ones per double).  Fixed combination tree: pairs, quads, half rows, rows of 16
+// (quad_perm / row_half_mirror / row_mirror leave every lane of a row with the row's sum), then
+// row 0 -> 1 and 2 -> 3 (row_bcast:15), rows 0+1 -> 2,3 (row_bcast:31); lane 63 holds the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;
+    v += dpp_move<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xf>(v);     // row_half_mirror
+    v += dpp_move<0x140, 0xf>(v);     // row_mirror
+    v += dpp_move<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3 (other rows receive 0)
+    v += dpp_move<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // Sum over a 1-D block (blockDim.x multiple of 64, <= 1024).  Result valid in thread 0.
@@ -1008,7 +1024,6 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
     const int row = blockIdx.x;
     const int M = SPECM ? SPECM : A.plan.M, nxs = SPECM ? 2 * SPECM : A.nxs;
     double* red = smem + 2 * (size_t)M;
-    double& s_mn = red[16];
     int* s_cnt = reinterpret_cast<int*>(red + 17);
 #if defined(HMG_ABL) && HMG_ABL == 5     // timing experiment: workgroup launch only
     if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = 1.0;
@@ -1081,17 +1096,22 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
             acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
         }
     }
+    // mass norm: wavefront sums (DPP), one LDS exchange, and EVERY thread adds the eight partials itself in
+    // wave order - no second reduction stage, no third barrier.  The two barriers also publish buf and the
+    // row scalars thread 0 wrote.
     {
-        const double tot = block_sum(acc, red);   // contains the barrier that publishes buf
-        if (threadIdx.x == 0) {
-            s_mn = A.do_norm ? tot : 1.0;
-            red[23] = -A.step / s_mn;             // u_j = Im F_j * this / kt_j
-        }
+        const double ws = wave_sum(acc);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+        __syncthreads();
     }
-    __syncthreads();
+    double tot = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) tot += red[w];
+    const double mnorm = A.do_norm ? tot : 1.0;
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
 #if defined(HMG_ABL) && (HMG_ABL == 1 || HMG_ABL == 4)     // timing experiments only: stop after phase A
-    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + s_mn;
+    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + mnorm;
     return;
 #endif
     // ---- phase B: in-place Stockham FFT of length M
@@ -1120,12 +1140,12 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
         else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
     }
 #if defined(HMG_ABL) && HMG_ABL == 2     // stop after phase B
-    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + s_mn;
+    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + mnorm;
     return;
 #endif
     // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm for the reachable modes
     // j = 1..jn, into smem[0..jn-1]
-    const double sc = red[23];
+    const double sc = -A.step / mnorm;            // u_j = Im F_j * this / kt_j
     double ua[MAXP], ub[MAXP];
     const int half = M / 2;
 #pragma unroll
