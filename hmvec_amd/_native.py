@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -19,6 +19,15 @@ c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
 
 class NativeError(RuntimeError):
     pass
+
+
+class HaloStageArgs(C.Structure):
+    """hmg_halo_stage_args (include/hmgrid.h): the halo-stage half of hmg_sigma2_massfn_halo."""
+    _fields_ = [("d_zs", C.c_void_p), ("d_delta", C.c_void_p), ("d_rho", C.c_void_p),
+                ("duffy_A", C.c_double), ("duffy_alpha", C.c_double), ("duffy_beta", C.c_double),
+                ("h", C.c_double), ("d_cs", C.c_void_p), ("d_rvir", C.c_void_p), ("d_rs", C.c_void_p),
+                ("d_nfw_series", C.c_void_p), ("d_drho1", C.c_void_p), ("delta2", C.c_double),
+                ("d_rho2", C.c_void_p), ("d_m2", C.c_void_p), ("d_r2", C.c_void_p)]
 
 
 class MassFnParams(C.Structure):
@@ -79,6 +88,8 @@ SIGNATURES = {
     "hmg_sigma2_prepare": [_P, _I, _I, _P, _P],
     "hmg_sigma2_prepared": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P],
     "hmg_sigma2_massfn": [_P, _I, _I, _I, _P, _P, _P, _P, _D, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P],
+    "hmg_sigma2_massfn_halo": [_P, _I, _I, _I, _P, _P, _P, _P, _D, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P,
+                               C.POINTER(HaloStageArgs)],
     "hmg_halo_stage": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P, _P, _P, _D, _P, _P, _P],
     "hmg_massfn": [_P, _I, _I, C.POINTER(MassFnParams), _P, _P, _P, _P, _P, _P],
     "hmg_halo_structure": [_P, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P],

@@ -225,7 +225,10 @@ __device__ __forceinline__ double block_sum_multi(const double (&v)[N], double* 
 // per-segment partial sums are combined in order by sigma2_combine_kernel.  Nothing of shape
 // (nz,nm,nq) is materialised (the reference builds 1.3 GB temporaries here).
 typedef double d4_t __attribute__((ext_vector_type(4)));
-constexpr int SIG_SEG_LEN = 80;    // k' values per segment (multiple of 16)
+#ifndef HMG_SIG_SEG_LEN
+#define HMG_SIG_SEG_LEN 80
+#endif
+constexpr int SIG_SEG_LEN = HMG_SIG_SEG_LEN;    // k' values per segment (multiple of 16)
 
 // out[c][r] = in[r][c] for r < rows, zero for rows <= r < rows_pad
 __global__ void transpose_pad_kernel(int rows, int rows_pad, int cols, const double* __restrict__ in,
@@ -321,6 +324,23 @@ __global__ __launch_bounds__(64, HMG_SIG_OCC) void sigma2_mfma_kernel(int nz, in
     }
 }
 
+__device__ __forceinline__ double sigma2_segment_sum(int n, int parts, const double* __restrict__ partial, size_t i, int w) {
+    // parts w, w+4, w+8, ... in order.  Sixteen loads are in flight per round (they do not depend on the
+    // running sum); positions past the end contribute +0.0, which leaves the sum's bits alone - a scalar
+    // tail loop here cost one memory round trip per leftover part (7 of them at nq = 10^4).
+    double s = 0.0;
+    for (int p = w; p < parts; p += 64) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int pp = p + 4 * u;
+            v[u] = pp < parts ? partial[(size_t)pp * n + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    return s;
+}
 // out[i] = sum_p partial[p][i] in a fixed order: 4 wavefronts per 64 outputs take interleaved
 // segments, then add up through LDS (wave 0, in wave order).
 __global__ __launch_bounds__(256) void sigma2_combine_kernel(int n, int parts,
@@ -329,19 +349,7 @@ __global__ __launch_bounds__(256) void sigma2_combine_kernel(int n, int parts,
     __shared__ double red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (i < n) {
-        // loads are independent of the running sum: issue them eight at a time
-        int p = w;
-        for (; p + 28 < parts; p += 32) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + 4 * u) * n + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; p < parts; p += 4) s += partial[(size_t)p * n + i];
-    }
+    const double s = i < n ? sigma2_segment_sum(n, parts, partial, (size_t)i, w) : 0.0;
     red[w][lane] = s;
     __syncthreads();
     if (w == 0 && i < n) out[i] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
@@ -428,53 +436,46 @@ __global__ void massfn_kernel(int nz, int nm, MassFnDev P, const double* __restr
 // Second stage of sigma^2 (the ordered sum over the k' segments, exactly sigma2_combine_kernel's) and
 // the mass function in ONE launch: a workgroup owns 64 consecutive masses of one redshift, sums the
 // partials of those and of the two neighbours the gradient stencil reaches, keeps the 66 values in
-// LDS, writes sigma2 and evaluates n(z,m), b(z,m) from LDS.  grid (ceil(nm/64), nz), 256 threads.
-__device__ __forceinline__ double sigma2_segment_sum(int n, int parts, const double* __restrict__ partial, size_t i, int w) {
-    double s = 0.0;
-    int p = w;
-    for (; p + 28 < parts; p += 32) {       // loads are independent of the running sum: eight at a time
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + 4 * u) * n + i];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; p < parts; p += 4) s += partial[(size_t)p * n + i];
-    return s;
-}
-__global__ __launch_bounds__(256) void sigma2_massfn_kernel(int nz, int nm, int parts, MassFnDev P,
-                                                            const double* __restrict__ partial /*[parts][nz*nm]*/,
-                                                            const double* __restrict__ ms,
-                                                            const double* __restrict__ lnm,
-                                                            const double* __restrict__ tz,
-                                                            double* __restrict__ s2, double* __restrict__ nzm,
-                                                            double* __restrict__ bh) {
-    __shared__ double red[4][66];
-    __shared__ double sig[66];
+// LDS, writes sigma2 and evaluates n(z,m), b(z,m) from LDS.  512 threads: wavefronts 0-3 take the four
+// interleaved part groups of the 64 masses, two lanes of wavefronts 4-7 those of the two neighbours (so
+// that no lane walks the parts twice).
+struct SigmaMassFnArgs {
+    int nz, nm, parts;
+    MassFnDev P;
+    const double *partial /*[parts][nz*nm]*/, *ms, *lnm, *tz;
+    double *s2, *nzm, *bh;
+};
+__device__ __forceinline__ void sigma2_massfn_block(const SigmaMassFnArgs& A, int z, int m0, double (*red)[66],
+                                                    double* sig) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int z = blockIdx.y, m0 = blockIdx.x * 64;
-    const int n = nz * nm;
-    // slot j <-> mass m0 - 1 + j (clamped to the row): lanes take j = lane, lanes 0,1 also j = 64, 65
-    for (int j = lane; j < 66; j += 64) {
+    const int nm = A.nm, n = A.nz * nm;
+    // slot j <-> mass m0 - 1 + j (clamped to the row)
+    const int j = w < 4 ? lane + 1 : (lane == 0 ? 0 : 65);
+    if (w < 4 || lane < 2) {
         const int m = min(max(m0 - 1 + j, 0), nm - 1);
-        red[w][j] = sigma2_segment_sum(n, parts, partial, (size_t)z * nm + m, w);
+        red[w & 3][j] = sigma2_segment_sum(n, A.parts, A.partial, (size_t)z * nm + m, w & 3);
     }
     __syncthreads();
     if (threadIdx.x < 66) {
-        const int j = threadIdx.x;
-        const double v = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
-        sig[j] = v;
-        const int m = m0 - 1 + j;
-        if (j >= 1 && j <= 64 && m < nm) s2[(size_t)z * nm + m] = v;
+        const int jj = threadIdx.x;
+        const double v = ((red[0][jj] + red[1][jj]) + red[2][jj]) + red[3][jj];
+        sig[jj] = v;
+        const int m = m0 - 1 + jj;
+        if (jj >= 1 && jj <= 64 && m < nm) A.s2[(size_t)z * nm + m] = v;
     }
     __syncthreads();
     const int m = m0 + threadIdx.x;
     if (threadIdx.x < 64 && m < nm) {
         double nn, bb;
-        massfn_point(P, z, m, nm, [&](int i) { return sig[i - m0 + 1]; }, ms, lnm, tz, nn, bb);
-        nzm[(size_t)z * nm + m] = nn;
-        bh[(size_t)z * nm + m] = bb;
+        massfn_point(A.P, z, m, nm, [&](int i) { return sig[i - m0 + 1]; }, A.ms, A.lnm, A.tz, nn, bb);
+        A.nzm[(size_t)z * nm + m] = nn;
+        A.bh[(size_t)z * nm + m] = bb;
     }
+}
+__global__ __launch_bounds__(512) void sigma2_massfn_kernel(SigmaMassFnArgs A) {
+    __shared__ double red[4][66];
+    __shared__ double sig[66];
+    sigma2_massfn_block(A, blockIdx.y, blockIdx.x * 64, red, sig);
 }
 
 // ---------------------------------------------------------------- A5: c(m,z), rvir(m,z)
@@ -785,28 +786,50 @@ __global__ void rows_from_mvir_kernel(int kind, int nz, int nm, const double* __
 // c, rvir, rs + the NFW series row + the mass conversion of one (z,m) per thread: the three
 // per-(z,m) launches that precede the profile kernels of a pass, in one (hmg_halo_stage).
 __device__ __forceinline__ void nfw_series_row(double c, double* __restrict__ a);
-__global__ void halo_stage_kernel(int nz, int nm, const double* __restrict__ ms, const double* __restrict__ zs,
-                                  const double* __restrict__ delta, const double* __restrict__ rho, double A,
-                                  double alpha, double beta, double h, double* __restrict__ cs,
-                                  double* __restrict__ rv, double* __restrict__ rs,
-                                  double* __restrict__ series /*[nz*nm][NFW_NS2] or null*/,
-                                  const double* __restrict__ d1, double delta2, const double* __restrict__ rho2,
-                                  double* __restrict__ m2, double* __restrict__ r2 /* both or neither */) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nz * nm) return;
-    const int z = idx / nm, m = idx - z * nm;
-    const double mm = ms[m];
-    const double c = A * pow(h * mm / 2.0e12, alpha) * pow(1.0 + zs[z], beta);
-    const double r = pow(3.0 * mm / 4.0 / M_PI / delta[z] / rho[z], 1.0 / 3.0);
-    cs[idx] = c;
-    rv[idx] = r;
-    rs[idx] = r / c;
-    if (m2) {
-        const double M2 = mdelta_solve(mm, c, d1[z] / (delta2 * rho2[z]));
-        m2[idx] = M2;
-        r2[idx] = cbrt(3.0 * M2 / 4.0 / M_PI / delta2 / rho2[z]);
+struct HaloStageArgs {
+    int nz, nm;
+    const double *ms, *zs, *delta, *rho;
+    double A, alpha, beta, h;
+    double *cs, *rv, *rs, *series /*[nz*nm][NFW_ROW] or null*/;
+    const double* d1;
+    double delta2;
+    const double* rho2;
+    double *m2, *r2 /* both or neither */;
+};
+__device__ __forceinline__ void halo_stage_point(const HaloStageArgs& H, int idx) {
+    const int z = idx / H.nm, m = idx - z * H.nm;
+    const double mm = H.ms[m];
+    const double c = H.A * pow(H.h * mm / 2.0e12, H.alpha) * pow(1.0 + H.zs[z], H.beta);
+    const double r = pow(3.0 * mm / 4.0 / M_PI / H.delta[z] / H.rho[z], 1.0 / 3.0);
+    H.cs[idx] = c;
+    H.rv[idx] = r;
+    H.rs[idx] = r / c;
+    if (H.m2) {
+        const double M2 = mdelta_solve(mm, c, H.d1[z] / (H.delta2 * H.rho2[z]));
+        H.m2[idx] = M2;
+        H.r2[idx] = cbrt(3.0 * M2 / 4.0 / M_PI / H.delta2 / H.rho2[z]);
     }
-    if (series) nfw_series_row(c, series + (size_t)idx * NFW_ROW);
+    if (H.series) nfw_series_row(c, H.series + (size_t)idx * NFW_ROW);
+}
+__global__ void halo_stage_kernel(HaloStageArgs H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < H.nz * H.nm) halo_stage_point(H, idx);
+}
+
+// Everything the constructor computes per (z,m), in ONE launch behind the sigma^2 contraction: plane 0 of
+// the grid is sigma2_massfn_kernel's work (needs the contraction's partial sums), plane 1 the halo stage
+// (needs only m and z).  The two do not depend on each other, so the halo stage's workgroups fill the
+// compute units the 8 x nz mass-function workgroups leave idle instead of waiting for a launch of their own.
+// grid (ceil(nm/64), nz, 2), 512 threads; plane 1 uses the first wavefront of each workgroup.
+__global__ __launch_bounds__(512) void ctor_stage_kernel(SigmaMassFnArgs A, HaloStageArgs H) {
+    __shared__ double red[4][66];
+    __shared__ double sig[66];
+    if (blockIdx.z == 0) {
+        sigma2_massfn_block(A, blockIdx.y, blockIdx.x * 64, red, sig);
+    } else if (threadIdx.x < 64) {
+        const int m = blockIdx.x * 64 + threadIdx.x;
+        if (m < H.nm) halo_stage_point(H, blockIdx.y * H.nm + m);
+    }
 }
 
 // ---------------------------------------------------------------- K4: profile integrand (F1)
@@ -2503,14 +2526,10 @@ int hmg_sigma2_prepared(hmg_ctx* c, int nz, int nm, int nq, const double* PT, co
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int hmg_sigma2_massfn(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq, const double* wq,
-                      const double* R, double tswitch, const hmg_massfn_params* p, const double* ms,
-                      const double* lnms, const double* tz, double* sigma2, double* nzm, double* bh) {
-    REQUIRE(c && PT && kq && wq && R && p && ms && lnms && sigma2 && nzm && bh, "NULL argument");
-    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
-    REQUIRE(p->mode == HMG_MF_SHETH_TORMEN || p->mode == HMG_MF_TINKER10, "unknown mass function");
-    REQUIRE(p->mode != HMG_MF_TINKER10 || tz, "Tinker mode needs d_tinker_z");
-    REQUIRE(nz <= 65535, "nz too large");
+// first stage of the contraction for hmg_sigma2_massfn / hmg_sigma2_massfn_halo: launches the matrix-core
+// kernel, returns the partial sums' buffer and the number of k' segments
+static int sigma2_partials(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq, const double* wq,
+                           const double* R, double tswitch, const double** partial_out, int* nseg_out) {
     const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
     const int ztile = sigma2_ztile(nz), nzp = sigma2_nzp(nz);
     if (ensure_scratch(c, 4, (size_t)nseg * nz * nm * 8)) return 1;
@@ -2524,9 +2543,57 @@ int hmg_sigma2_massfn(hmg_ctx* c, int nz, int nm, int nq, const double* PT, cons
         hipLaunchKernelGGL(sigma2_mfma_kernel<1>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
                            PT, kq, wq, R, tswitch, partial);
     HIP_TRY(hipGetLastError());
+    *partial_out = partial;
+    *nseg_out = nseg;
+    return 0;
+}
+static int sigma2_massfn_check(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq,
+                               const double* wq, const double* R, const hmg_massfn_params* p, const double* ms,
+                               const double* lnms, const double* tz, double* sigma2, double* nzm, double* bh) {
+    REQUIRE(c && PT && kq && wq && R && p && ms && lnms && sigma2 && nzm && bh, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
+    REQUIRE(p->mode == HMG_MF_SHETH_TORMEN || p->mode == HMG_MF_TINKER10, "unknown mass function");
+    REQUIRE(p->mode != HMG_MF_TINKER10 || tz, "Tinker mode needs d_tinker_z");
+    REQUIRE(nz <= 65535, "nz too large");
+    return 0;
+}
+int hmg_sigma2_massfn(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq, const double* wq,
+                      const double* R, double tswitch, const hmg_massfn_params* p, const double* ms,
+                      const double* lnms, const double* tz, double* sigma2, double* nzm, double* bh) {
+    if (sigma2_massfn_check(c, nz, nm, nq, PT, kq, wq, R, p, ms, lnms, tz, sigma2, nzm, bh)) return 1;
+    const double* partial;
+    int nseg;
+    if (sigma2_partials(c, nz, nm, nq, PT, kq, wq, R, tswitch, &partial, &nseg)) return 1;
     MassFnDev P{p->mode, p->deltac, p->st_A, p->st_a, p->st_p, p->rho_m0, p->lnm_uniform, p->lnm_step};
-    hipLaunchKernelGGL(sigma2_massfn_kernel, dim3((nm + 63) / 64, nz), dim3(256), 0, c->stream, nz, nm, nseg, P,
-                       (const double*)partial, ms, lnms, tz, sigma2, nzm, bh);
+    SigmaMassFnArgs A{nz, nm, nseg, P, partial, ms, lnms, tz, sigma2, nzm, bh};
+    hipLaunchKernelGGL(sigma2_massfn_kernel, dim3((nm + 63) / 64, nz), dim3(512), 0, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static int halo_stage_check(hmg_ctx* c, int nz, int nm, const double* ms, const hmg_halo_stage_args* h,
+                            HaloStageArgs* H) {
+    REQUIRE(c && ms && h && h->d_zs && h->d_delta && h->d_rho && h->d_cs && h->d_rvir && h->d_rs, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    REQUIRE((h->d_m2 == nullptr) == (h->d_r2 == nullptr), "pass both d_m2 and d_r2 or neither");
+    REQUIRE(!h->d_m2 || (h->d_drho1 && h->d_rho2), "the mass conversion needs d_drho1 and d_rho2");
+    *H = HaloStageArgs{nz, nm, ms, h->d_zs, h->d_delta, h->d_rho, h->duffy_A, h->duffy_alpha, h->duffy_beta, h->h,
+                       h->d_cs, h->d_rvir, h->d_rs, h->d_nfw_series, h->d_drho1, h->delta2, h->d_rho2, h->d_m2,
+                       h->d_r2};
+    return 0;
+}
+int hmg_sigma2_massfn_halo(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq,
+                           const double* wq, const double* R, double tswitch, const hmg_massfn_params* p,
+                           const double* ms, const double* lnms, const double* tz, double* sigma2, double* nzm,
+                           double* bh, const hmg_halo_stage_args* h) {
+    if (sigma2_massfn_check(c, nz, nm, nq, PT, kq, wq, R, p, ms, lnms, tz, sigma2, nzm, bh)) return 1;
+    HaloStageArgs H;
+    if (halo_stage_check(c, nz, nm, ms, h, &H)) return 1;
+    const double* partial;
+    int nseg;
+    if (sigma2_partials(c, nz, nm, nq, PT, kq, wq, R, tswitch, &partial, &nseg)) return 1;
+    MassFnDev P{p->mode, p->deltac, p->st_A, p->st_a, p->st_p, p->rho_m0, p->lnm_uniform, p->lnm_step};
+    SigmaMassFnArgs A{nz, nm, nseg, P, partial, ms, lnms, tz, sigma2, nzm, bh};
+    hipLaunchKernelGGL(ctor_stage_kernel, dim3((nm + 63) / 64, nz, 2), dim3(512), 0, c->stream, A, H);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2569,12 +2636,10 @@ int hmg_halo_stage(hmg_ctx* c, int nz, int nm, const double* ms, const double* z
                    const double* rho, double A, double alpha, double beta, double h, double* cs, double* rv,
                    double* rs, double* nfw_series, const double* drho1, double delta2, const double* rho2,
                    double* m2, double* r2) {
-    REQUIRE(c && ms && zs && delta && rho && cs && rv && rs, "NULL argument");
-    REQUIRE(nz > 0 && nm > 0, "empty grid");
-    REQUIRE((m2 == nullptr) == (r2 == nullptr), "pass both d_m2 and d_r2 or neither");
-    REQUIRE(!m2 || (drho1 && rho2), "the mass conversion needs d_drho1 and d_rho2");
-    hipLaunchKernelGGL(halo_stage_kernel, grid1d((size_t)nz * nm, 64), dim3(64), 0, c->stream, nz, nm, ms, zs,
-                       delta, rho, A, alpha, beta, h, cs, rv, rs, nfw_series, drho1, delta2, rho2, m2, r2);
+    const hmg_halo_stage_args a{zs, delta, rho, A, alpha, beta, h, cs, rv, rs, nfw_series, drho1, delta2, rho2, m2, r2};
+    HaloStageArgs H;
+    if (halo_stage_check(c, nz, nm, ms, &a, &H)) return 1;
+    hipLaunchKernelGGL(halo_stage_kernel, grid1d((size_t)nz * nm, 64), dim3(64), 0, c->stream, H);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -370,25 +370,32 @@ class HaloModel(Cosmology):
         par, d_lnm, d_tz, d_delta, d_rho = self._dcache["mf_in"]
         self._d_nzm, self._d_bh = self._buf("nzm", (nz, nm)), self._buf("bh", (nz, nm))
         d_ms = self._d_ms()
-        ctx.call("hmg_sigma2_massfn", nz, nm, d_kq.size, d_PT.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
-                 float(self.p["Wkr_taylor_switch"]), C.byref(par), d_ms.ptr, d_lnm.ptr, nat.ptr(d_tz),
-                 self._d_sigma2.ptr, self._d_nzm.ptr, self._d_bh.ptr)
-        self._aux_done()
-        # c(z,m), rvir(z,m), rs(z,m): independent of sigma2 -> main lane, ahead of the profile kernels
+        # c(z,m), rvir(z,m), rs(z,m), the series rows of the analytic NFW kernel and the vir -> 200c mass
+        # conversion the Battaglia profiles need: one thread per (z,m), independent of sigma2
         sfx = self.mdef
         self._d_cs, self._d_rvir, self._d_rs = (self._buf(k, (nz, nm)) for k in ("cs", "rvir", "rs"))
-        # ... together with the series rows of the analytic NFW kernel and the vir -> 200c mass
-        # conversion the Battaglia profiles need (all one thread per (z,m): one launch)
         self._d_nfw_series = self._buf("nfw_series", (nz, nm, nat.NFW_SERIES_STRIDE))
         m2, r2 = self._buf("m200c", (nz, nm)), self._buf("r200c", (nz, nm))
         d_drho1 = self._d_drho1()
         d_rhoc = self._dev("rhocz", lambda: self.rho_critical_z(self.zs))
-        ctx = self._main()
-        ctx.call("hmg_halo_stage", nz, nm, self._d_ms().ptr, self._d_zs().ptr, d_delta.ptr, d_rho.ptr,
-                 float(self.p["duffy_A_" + sfx]), float(self.p["duffy_alpha_" + sfx]),
-                 float(self.p["duffy_beta_" + sfx]), float(self.h),
-                 self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr, self._d_nfw_series.ptr,
-                 d_drho1.ptr, 200.0, d_rhoc.ptr, m2.ptr, r2.ptr)
+        sig_args = (nz, nm, d_kq.size, d_PT.ptr, d_kq.ptr, d_wq.ptr, d_R.ptr,
+                    float(self.p["Wkr_taylor_switch"]), C.byref(par), d_ms.ptr, d_lnm.ptr, nat.ptr(d_tz),
+                    self._d_sigma2.ptr, self._d_nzm.ptr, self._d_bh.ptr)
+        duffy = tuple(float(self.p[f"duffy_{k}_{sfx}"]) for k in ("A", "alpha", "beta"))
+        if not self._use_lanes:
+            # one launch behind the contraction: mass function and halo stage side by side
+            halo = nat.HaloStageArgs(self._d_zs().ptr, d_delta.ptr, d_rho.ptr, *duffy, float(self.h),
+                                     self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr, self._d_nfw_series.ptr,
+                                     d_drho1.ptr, 200.0, d_rhoc.ptr, m2.ptr, r2.ptr)
+            ctx.call("hmg_sigma2_massfn_halo", *sig_args, C.byref(halo))
+        else:
+            # two-lane scheme: n, b on the auxiliary lane, the halo stage on the main lane ahead of the profiles
+            ctx.call("hmg_sigma2_massfn", *sig_args)
+            self._aux_done()
+            ctx = self._main()
+            ctx.call("hmg_halo_stage", nz, nm, d_ms.ptr, self._d_zs().ptr, d_delta.ptr, d_rho.ptr,
+                     *duffy, float(self.h), self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr,
+                     self._d_nfw_series.ptr, d_drho1.ptr, 200.0, d_rhoc.ptr, m2.ptr, r2.ptr)
         self._m200c_valid = True
 
     def get_fsigmaz(self):

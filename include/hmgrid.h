@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMG_ABI_VERSION 3
+#define HMG_ABI_VERSION 4
 
 typedef struct hmg_ctx hmg_ctx;
 
@@ -153,6 +153,25 @@ int hmg_halo_stage(hmg_ctx* ctx, int nz, int nm, const double* d_ms, const doubl
                    double* d_cs, double* d_rvir, double* d_rs, double* d_nfw_series,
                    const double* d_drho1 /*[nz]*/, double delta2, const double* d_rho2 /*[nz]*/,
                    double* d_m2, double* d_r2);
+
+/* Everything the constructor computes per (z,m) - hmg_sigma2_massfn and hmg_halo_stage (hmvec/hmvec.py:87-91,
+ * 121-185 and :163-176, 225-227) - behind ONE launch after the sigma^2 contraction: the halo stage does not
+ * depend on sigma^2, so its workgroups run beside the mass function's instead of waiting for a launch of
+ * their own.  Same arithmetic, same results bit for bit as the two separate calls.                      */
+typedef struct {
+    const double *d_zs, *d_delta /*[nz]*/, *d_rho /*[nz]*/;
+    double duffy_A, duffy_alpha, duffy_beta, h;
+    double *d_cs, *d_rvir, *d_rs, *d_nfw_series /* or NULL */;
+    const double* d_drho1 /*[nz]*/;
+    double delta2;
+    const double* d_rho2 /*[nz]*/;
+    double *d_m2, *d_r2 /* both or NULL */;
+} hmg_halo_stage_args;                 /* the arguments of hmg_halo_stage after d_ms, in its order */
+int hmg_sigma2_massfn_halo(hmg_ctx* ctx, int nz, int nm, int nq, const double* d_PT,
+                           const double* d_kq, const double* d_wq, const double* d_R, double taylor_switch,
+                           const hmg_massfn_params* h_par, const double* d_ms, const double* d_lnms,
+                           const double* d_tinker_z, double* d_sigma2, double* d_nzm, double* d_bh,
+                           const hmg_halo_stage_args* h_halo);
 
 /* ---- A7: mass-definition conversion -------------------------------------------------
  * Replaces mdelta_from_mdelta (hmvec/hmvec.py:748-798): the root in ln M2 of

@@ -374,3 +374,25 @@ def test_compile_time_plan_equals_run_time_plan(monkeypatch):
         assert np.array_equal(a, b)
     o = oracle_for(h, zs, ks, ms, 5000, 8)
     assert np.max(np.abs(out["0"][1] - o.uk_profiles["electron"])) < 1e-12
+
+
+@pytest.mark.parametrize("nz,nm", [(3, 7), (2, 64), (5, 130), (1, 65)])
+def test_constructor_stage_in_one_launch_equals_the_two_launches(nz, nm, monkeypatch):
+    """hmg_sigma2_massfn_halo (mass function and halo stage side by side in one launch, what the
+    constructor issues) against hmg_sigma2_massfn + hmg_halo_stage (what the two-lane scheme issues):
+    every (z,m) array bit for bit, across partial 64-mass tiles."""
+    import hmvec_amd as hm
+    zs = np.linspace(0.1, 2.5, nz)
+    ms = np.geomspace(3e10, 1e16, nm)
+    ks = np.geomspace(1e-3, 30, 17)
+    one = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    monkeypatch.setenv("HMG_LANES", "1")
+    two = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    assert not one._use_lanes and two._use_lanes
+    for name in ("sigma2", "nzm", "bh"):
+        assert np.array_equal(getattr(one, name), getattr(two, name)), name
+    for name in ("_d_cs", "_d_rvir", "_d_rs", "_d_nfw_series"):
+        assert np.array_equal(getattr(one, name).numpy(), getattr(two, name).numpy()), name
+    for name in ("m200c", "r200c"):
+        assert np.array_equal(one._buf(name, (nz, nm)).numpy(), two._buf(name, (nz, nm)).numpy()), name
+    assert np.array_equal(one.uk_profiles["nfw"], two.uk_profiles["nfw"])
