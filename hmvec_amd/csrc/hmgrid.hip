@@ -2664,8 +2664,8 @@ int hmg_nfw_analytic(hmg_ctx* c, int nz, int nm, int nk, const double* cs, const
     int threads = 256, ktile = 4096;
     if (const char* e = getenv("HMG_NFW_THREADS")) threads = atoi(e);
     if (const char* e = getenv("HMG_NFW_KTILE")) ktile = atoi(e);
-    REQUIRE(threads == 64 || threads == 128 || threads == 256, "HMG_NFW_THREADS must be 64/128/256");
-    REQUIRE(ktile >= threads && ktile % threads == 0, "HMG_NFW_KTILE must be a multiple of the block size");
+    REQUIRE(threads >= 64 && threads <= 256 && threads % 64 == 0, "HMG_NFW_THREADS must be 64/128/192/256");
+    REQUIRE(ktile >= threads, "HMG_NFW_KTILE must not be smaller than the block size");
     const size_t blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
     REQUIRE(blocks <= 2147483647u, "grid too large");
     const double* acoef = series;

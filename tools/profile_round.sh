@@ -3,16 +3,14 @@
 #   gpurun_out/prof/config3_bench.json          bench.py JSON line (default run, with cpu_baseline)
 #   gpurun_out/prof/config3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
 #   gpurun_out/prof/pmc_{fetch,write}_counter_collection.csv + pmc_traffic.json
+#   gpurun_out/prof/sq_issue_counters.{json,txt}  (tools/pmc_kernel.sh)
+# The counter passes run first and their summaries are installed under profiles/$ROUND/ on the box before the
+# bench line is taken, so the line's roofline numbers come from this build's own counters.
 # Copy them into profiles/rNN/ afterwards.  PMC passes run separately from the trace (gpurun rule).
 set -e
 ROOT="$GRAFT_REPO_ROOT"; [ -z "$ROOT" ] && ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof; mkdir -p $OUT
-python3 bench.py > $OUT/config3_bench.json
-echo "bench done"
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber > $OUT/kt.log 2>&1
-cp $OUT/kt/k_kernel_stats.csv $OUT/config3_kernel_stats.csv
-echo "kernel trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph > $OUT/pmc_$c.log 2>&1
 done
@@ -48,3 +46,16 @@ json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 for k, v in res["kernels"].items():
     print(f"{v['hbm_bytes_per_launch_corrected']/1e6:10.1f} MB  {k}")
 PY
+# SQ issue counters (five more passes), then install both summaries where bench.py reads them, so that the
+# bench line below is derived from the counters of THIS build on THIS box
+ROUND=${ROUND:-r02}
+bash tools/pmc_kernel.sh > $OUT/sq_issue_counters.txt
+cp gpurun_out/pmc_sq/sq_issue_counters.json $OUT/sq_issue_counters.json
+mkdir -p profiles/$ROUND
+cp $OUT/pmc_traffic.json $OUT/sq_issue_counters.json profiles/$ROUND/
+echo "counters done"
+python3 bench.py > $OUT/config3_bench.json
+echo "bench done"
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber > $OUT/kt.log 2>&1
+cp $OUT/kt/k_kernel_stats.csv $OUT/config3_kernel_stats.csv
+echo "kernel trace done"
