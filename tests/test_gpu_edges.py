@@ -88,6 +88,18 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.hmg_massfn(ctx.handle, 1, 4, C.byref(par), d.ptr, d.ptr, d.ptr, None, d.ptr, d.ptr) != 0
     assert b"unknown mass function" in lib.hmg_last_error()
     assert lib.hmg_lane_set(ctx.handle, 99) != 0
+    # the one-launch constructor stage: both halves are validated before anything is launched
+    ok = nat.MassFnParams(mode=nat.MF_SHETH_TORMEN, deltac=1.686, st_A=0.3222, st_a=0.707, st_p=0.3, rho_m0=1.0)
+    sig = (1, 4, 8, d.ptr, d.ptr, d.ptr, d.ptr, 0.01, C.byref(ok), d.ptr, d.ptr, None, d.ptr, d.ptr, d.ptr)
+    assert lib.hmg_sigma2_massfn_halo(ctx.handle, *sig, None) != 0
+    assert b"NULL" in lib.hmg_last_error()
+    halo = nat.HaloStageArgs(d.ptr, d.ptr, d.ptr, 1.0, 0.1, 0.1, 0.7, d.ptr, d.ptr, d.ptr, None, None, 200.0, None,
+                             d.ptr, None)
+    assert lib.hmg_sigma2_massfn_halo(ctx.handle, *sig, C.byref(halo)) != 0
+    assert b"both d_m2 and d_r2" in lib.hmg_last_error()
+    halo.d_r2 = d.ptr
+    assert lib.hmg_sigma2_massfn_halo(ctx.handle, *sig, C.byref(halo)) != 0
+    assert b"d_drho1 and d_rho2" in lib.hmg_last_error()
     h = C.c_void_p()
     assert lib.hmg_ctx_create(12345, C.byref(h)) != 0
     assert b"out of range" in lib.hmg_last_error()
