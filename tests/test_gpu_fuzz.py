@@ -3,6 +3,8 @@ ranges (low-mass/high-z halos with large concentrations, 1e16 halos with c ~ 1, 
 every branch of the NFW evaluation - both series tiers, the Si/Ci closed form and the collapsed
 large-argument form - is hit), mass definition, mass function, feedback family, FFT lengths on both
 the workgroup-FFT and the rocFFT route, HOD correlation mode, miscentred centrals, pressure."""
+import os
+
 import numpy as np
 import pytest
 import scipy.constants as sc
@@ -39,7 +41,8 @@ def draw(seed):
     return cfg
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+# HMG_FUZZ_SEEDS=N widens the sweep for a one-off soak run (the suite itself keeps 16 cases)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("HMG_FUZZ_SEEDS", "16")))))
 def test_random_configuration_against_oracle(seed, alpha_table):
     import hmvec_amd as hm
     from hmvec_amd.params import battaglia_defaults
