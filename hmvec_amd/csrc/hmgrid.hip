@@ -1972,6 +1972,13 @@ __global__ __launch_bounds__(256) void fn2d_kernel(FnArgs A) {
             pow(10.0, (s.d0 + s.da * am1) * d) / (1.0 + pow(10.0, -(s.g0 + s.ga * am1) * d));
         break;
     }
+    case HMG_FN_MHALO_STELLAR_CORE: {
+        const double lms = X(0), am1 = X(1) - 1.0;
+        const double d = lms - (par[0] + par[1] * am1);
+        y = -0.5 + (par[2] + par[3] * am1) + (par[4] + par[5] * am1) * d +
+            pow(10.0, (par[8] + par[9] * am1) * d) / (1.0 + pow(10.0, -(par[6] + par[7] * am1) * d));
+        break;
+    }
     case HMG_FN_HOD_NC:
         y = 0.5 * (1.0 - erf((X(1) - X(0)) / (sqrt(2.0) * par[0])));
         break;
@@ -3145,8 +3152,8 @@ int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const 
 // ---- function mirrors ------------------------------------------------------------------------
 int hmg_fn2d(hmg_ctx* c, int op, int rows, int cols, int nin, const double* const* in, const int* sr,
              const int* sc, const double* par, int npar, double* out) {
-    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4, 2, 3};
-    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4, 1, 3};
+    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4, 2, 3, 2};
+    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4, 1, 3, 10};
     REQUIRE(c && in && sr && sc && out, "NULL argument");
     REQUIRE(op >= 0 && op < HMG_FN_COUNT, "unknown function id");
     REQUIRE(rows > 0 && cols > 0, "empty grid");

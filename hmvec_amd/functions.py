@@ -24,7 +24,7 @@ from .params import battaglia_defaults, default_params
 (FN_TINKER_BIAS, FN_TINKER_FNU, FN_MHALO_STELLAR, FN_HOD_NC, FN_HOD_NS, FN_HOD_MFUNC, FN_HOD_NSNSM1,
  FN_HOD_NCNS, FN_FCON, FN_RHO_NFW, FN_R_FROM_M, FN_DUFFY, FN_BATT_FIT, FN_RHO_GAS_X, FN_RHO_GAS_R,
  FN_PE_X, FN_PE_R, FN_NGAL_INTEGRAND, FN_A2Z, FN_MDELTA, FN_BG_INTEGRAND, FN_ST_FSIGMA, FN_TINKER_FSIGMA, FN_WKR,
- FN_LINCOMB3) = range(25)
+ FN_LINCOMB3, FN_MHALO_STELLAR_CORE) = range(26)
 
 _ctx_override = None
 
@@ -159,6 +159,12 @@ def Mhalo_stellar(z, log10mstellar):
     lms = np.asarray(log10mstellar, dtype=np.float64)
     lms = lms.reshape(-1, lms.shape[-1]) if lms.ndim else lms.reshape(1, 1)
     return fn2d(FN_MHALO_STELLAR, [z, lms]).reshape(z.size, lms.shape[-1])
+
+
+def Mhalo_stellar_core(log10mstellar, a, Mstar00, Mstara, M1, M1a, beta0, beta_a, gamma0, gamma_a, delta0, delta_a):
+    """The Behroozi+10 relation with explicit parameters (hmvec/hmvec.py:648-657); operands broadcast."""
+    return fn2d(FN_MHALO_STELLAR_CORE, [log10mstellar, a],
+                [Mstar00, Mstara, M1, M1a, beta0, beta_a, gamma0, gamma_a, delta0, delta_a])
 
 
 def Mstellar_halo(z, log10mhalo):
@@ -328,6 +334,7 @@ def P_e(r, m200critz, z, omb, omm, rhocritz, alpha=default_params["battaglia_pre
 
 
 __all__ = ["duffy_concentration", "R_from_M", "Fcon", "rhoscale_nfw", "rho_nfw", "rho_nfw_x", "a2z",
-           "mdelta_from_mdelta", "mdelta_from_mdelta_unvectorized", "Mhalo_stellar", "Mstellar_halo", "avg_Nc",
+           "mdelta_from_mdelta", "mdelta_from_mdelta_unvectorized", "Mhalo_stellar", "Mhalo_stellar_core",
+           "Mstellar_halo", "avg_Nc",
            "avg_Ns", "avg_NsNsm1", "avg_NcNs", "hod_default_mfunc", "ngal_from_mthresh", "battaglia_gas_fit",
            "rho_gas", "rho_gas_generic", "rho_gas_generic_x", "P_e", "P_e_generic", "P_e_generic_x"]

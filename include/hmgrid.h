@@ -360,7 +360,9 @@ int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, co
 #define HMG_FN_WKR           23  /* in k, R; par taylor_switch: Fourier top-hat W(kR)    cosmology.py:30-38 */
 #define HMG_FN_LINCOMB3      24  /* in X0, X1, X2; par a, b, c -> a X0 + b X1 + c X2
                                     (total_matter_power_spectrum etc.)                 cosmology.py:599-658 */
-#define HMG_FN_COUNT         25
+#define HMG_FN_MHALO_STELLAR_CORE 25 /* in log10mstellar, a; par Mstar00, Mstara, M1, M1a, beta0, beta_a, gamma0,
+                                       gamma_a, delta0, delta_a                         hmvec.py:648-657 */
+#define HMG_FN_COUNT         26
 #define HMG_FN_MAXIN   6
 #define HMG_FN_MAXPAR 16
 int hmg_fn2d(hmg_ctx* ctx, int op, int rows, int cols, int nin, const double* const* h_d_in,

@@ -18,7 +18,8 @@ TOL = 2e-13          # generic pow/exp/log on two different libms
 
 def test_package_exports_reference_names():
     import hmvec_amd as hm
-    for name in ("HaloModel", "duffy_concentration", "R_from_M", "Mstellar_halo", "Mhalo_stellar", "avg_Nc", "avg_Ns",
+    for name in ("HaloModel", "duffy_concentration", "R_from_M", "Mstellar_halo", "Mhalo_stellar", "Mhalo_stellar_core",
+                 "avg_Nc", "avg_Ns",
                  "avg_NsNsm1", "avg_NcNs", "hod_default_mfunc", "Fcon", "rhoscale_nfw", "rho_nfw_x", "rho_nfw",
                  "mdelta_from_mdelta", "mdelta_from_mdelta_unvectorized", "battaglia_gas_fit", "rho_gas",
                  "rho_gas_generic", "rho_gas_generic_x", "P_e", "P_e_generic", "P_e_generic_x", "a2z",
@@ -68,6 +69,13 @@ def test_hod_functions():
     lmh, zc, thr = np.log10(MS)[None, :], Z[:, None], G["hod_thr"]
     assert rel_err(hm.Mhalo_stellar(U["shmr_z"], U["shmr_logmstar"]), U["shmr_Mhalo_stellar"]) < TOL
     assert np.max(np.abs(hm.Mstellar_halo(U["shmr_z"], U["shmr_logmhalo"]) - U["shmr_Mstellar_halo"])) < 1e-12
+    # the explicit-parameter core (hmvec/hmvec.py:648-657) with the two table-2 sets reproduces the same golden rows
+    zz = np.asarray(U["shmr_z"]).reshape(-1, 1)
+    lo = (10.72, 0.55, 12.35, 0.28, 0.44, 0.18, 1.56, 2.51, 0.57, 0.17)
+    hi = (11.09, 0.56, 12.27, -0.84, 0.65, 0.31, 1.12, -0.53, 0.56, -0.12)
+    core = np.where(zz <= 0.8, hm.Mhalo_stellar_core(U["shmr_logmstar"], 1.0 / (1.0 + zz), *lo),
+                    hm.Mhalo_stellar_core(U["shmr_logmstar"], 1.0 / (1.0 + zz), *hi))
+    assert rel_err(core, U["shmr_Mhalo_stellar"]) < TOL
     Nc = hm.avg_Nc(lmh, zc, thr, 0.2)
     assert np.allclose(Nc, G["avg_Nc"], rtol=1e-11, atol=1e-300)
     Ns = hm.avg_Ns(lmh, zc, thr, G["avg_Nc"], 0.2, 1.0, 9.04, 0.74, 1.65, 0.59)
