@@ -33,6 +33,7 @@ class AnalyticBackground:
         self.w0 = float(w0)
         self.wa = float(wa)
         self.YHe = 0.2454 if YHe is None else YHe
+        self._chi_memo = {}
 
     def _E(self, z):
         z = np.asarray(z, dtype=np.float64)
@@ -48,10 +49,23 @@ class AnalyticBackground:
 
     def _chi_flat(self, z):
         z = np.asarray(z, dtype=np.float64)
+        # chi(z) is asked for the same few redshift vectors over and over (every lensing window, every
+        # Limber projection): the last results are kept, keyed by the redshifts and the parameters
+        key = None
+        if z.size <= 4096:
+            key = (z.shape, z.tobytes(), self.H0, self.omm, self.omk, self.w0, self.wa)
+            hit = self._chi_memo.get(key)
+            if hit is not None:
+                return hit.copy()
         zz = np.atleast_1d(z)[..., None]
         nodes = 0.5 * zz * (_GL_X + 1.0)
         val = 0.5 * zz[..., 0] * np.sum(_GL_W / self._E(nodes), axis=-1)
-        return (C_KMS / self.H0) * val.reshape(z.shape)
+        out = (C_KMS / self.H0) * val.reshape(z.shape)
+        if key is not None:
+            if len(self._chi_memo) >= 64:
+                self._chi_memo.pop(next(iter(self._chi_memo)))
+            self._chi_memo[key] = np.array(out, copy=True)
+        return out
 
     def comoving_radial_distance(self, z):
         return self._chi_flat(z)
