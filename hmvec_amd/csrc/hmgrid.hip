@@ -1110,7 +1110,10 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
 #endif
         const cplx y = cplx{xv.x * r0, xv.y * r1};
         if (pruned) {
-            for (int t = 0; t < R0; ++t) buf[R0 * p + t] = y;
+            // the R0 copies go out in an order rotated by lane/4: with t the same in every lane, lanes l and l+4
+            // (64 B apart) hit the same LDS banks and every one of these 16-B stores takes two passes
+            const int rot = (threadIdx.x >> 2);
+            for (int t = 0; t < R0; ++t) buf[R0 * p + (SPECM ? ((t + rot) & 3) : (t + rot) % R0)] = y;
         } else {
             buf[p] = y;
         }
