@@ -80,6 +80,14 @@ def spawn_ranks(args, argv):
              for r in range(n)]
     out0 = procs[0].communicate()[0].decode()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if os.environ.get("HMG_COMM") == "host-rehearsal":      # the rehearsal transport's last-round files
+        import glob
+        pat = f"hmg_reh_{port}_{os.getpid()}_w{n}_pp{os.getpid()}_s*"
+        for f in glob.glob(os.path.join(os.environ.get("HMG_REHEARSAL_DIR", "/dev/shm"), pat)):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
     sys.stdout.write(out0)
     sys.stdout.flush()
     if any(rcs):
@@ -280,7 +288,14 @@ def main():
     ctx = nat.Context(local_rank)
     tag = os.environ.get("HMG_LAUNCH_TAG") or \
         f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'solo')}"
-    comm = RcclComm(ctx, rank, world, tag)
+    transport = os.environ.get("HMG_COMM", "rccl")
+    if transport == "host-rehearsal" and world > 1:
+        # functional rehearsal of the N > 1 flow without RCCL (e.g. two ranks on one device): labelled in the line
+        from hmvec_amd.dist import HostRehearsalComm
+        comm = HostRehearsalComm(ctx, rank, world, tag)
+    else:
+        transport = "rccl"
+        comm = RcclComm(ctx, rank, world, tag)
     rccl_rank, rccl_ranks = comm.info()
 
     mthr = 10 ** 10.5 + zloc * 0.0
@@ -515,7 +530,7 @@ def main():
     out = {
         "metric": "(z,m,k) grid-points/sec for P_1h+P_2h",
         "value": pts * K / dt_max, "unit": "grid-points/s",
-        "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
+        "n_gpus": world, "rccl_ranks": rccl_ranks if transport == "rccl" else 0, "transport": transport, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
         "host_issue_ms_per_step": t_issue / K * 1e3, "preconditioning_steps": PRECONDITION,
         "launch_mode": ("hip-graph replay" if use_graph else "eager launches") + (", lanes" if args.lanes else ""),
         "kernel_events": f"HIP events around the three large kernels on every {BRACKET_EVERY}th timed step"

@@ -68,3 +68,36 @@ def test_gather_overlaps_on_its_own_lane_and_stays_ordered(tmp_path, monkeypatch
         assert np.allclose(final[p][1], ref.get_power_2halo(*p), rtol=1e-12, atol=0), p
     comm.close()
     ctx.close()
+
+
+def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path):
+    """The N > 1 data path minus RCCL itself (which refuses two ranks on one device): two processes, each
+    with the model of its z-slab, exchange through the file transport of HostRehearsalComm; what the
+    gather leaves in EVERY rank's full-grid buffers is, bit for bit, what one process computes on the
+    full redshift grid - slabs land in place and a slab reproduces its rows of the full grid exactly."""
+    import subprocess
+    import sys
+    import hmvec_amd as hm
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "helpers", "rehearsal_rank.py")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"t{os.getpid()}", str(tmp_path), outs[r]])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    zs = np.linspace(0.1, 2.6, 8)
+    ms = np.geomspace(2e10, 1e16, 96)
+    ks = np.geomspace(1e-3, 50, 384)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000)
+    h.add_hod("g", mthresh=10 ** (10.3 + 0.1 * zs))
+    pairs = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("g", "electron"), ("nfw", "electron")]
+    blk = h.spectra_block(pairs)          # the same batched mass-integral launch the ranks use
+    blk.compute()
+    ref = {p: (a.copy(), b.copy()) for p, (a, b) in blk.fetch().items()}
+    for r in range(2):
+        got = np.load(outs[r])
+        assert len(got.files) == 2 * len(pairs)
+        for key in got.files:
+            a, b, i = key.split("|")
+            assert np.array_equal(got[key], ref[(a, b)][int(i)]), (r, key)

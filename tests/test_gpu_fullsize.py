@@ -44,12 +44,17 @@ def test_zslab_equals_full_grid(full):
     zs, ms, ks = grids()
     lo, hi = 12, 16
     slab = build(zs[lo:hi], ms, ks)
+    # a fresh full-grid model with the same call sequence as the slab: a spectrum can come from the one-pair
+    # kernel or from a batched launch depending on what was asked before (per-pair cache, free riders), and the
+    # two sum in different orders (~1e-16), so the module fixture with its history is not the like-for-like partner
+    full = build(zs, ms, ks)
     assert np.array_equal(slab.sigma2, full.sigma2[lo:hi])
     assert np.array_equal(slab.nzm, full.nzm[lo:hi])
-    for a, b in (("nfw", "nfw"), ("g", "g")):
+    # (the reference's own slab runs differ by ~7e-15 in the electron spectra - its secant solver stops on a
+    # grid-wide test; here the mass conversion is solved per (z,m), so these are bit-equal too)
+    assert np.array_equal(slab.uk_profiles["electron"], full.uk_profiles["electron"][lo:hi])
+    for a, b in (("nfw", "nfw"), ("g", "g"), ("electron", "electron"), ("g", "electron"), ("nfw", "electron")):
         assert np.array_equal(slab.get_power(a, b), full.get_power(a, b)[lo:hi]), (a, b)
-    for a, b in (("electron", "electron"), ("g", "electron")):
-        assert np.allclose(slab.get_power(a, b), full.get_power(a, b)[lo:hi], rtol=1e-13, atol=0), (a, b)
 
 
 def test_two_halo_consistency_and_damping(full):

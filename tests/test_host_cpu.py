@@ -157,3 +157,32 @@ def test_bench_launcher_dry_run_and_failure_propagation():
         r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                            env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "rank exit codes" in r.stderr
+
+
+def _rehearsal_rank(rank, world, tag, directory, q):
+    from hmvec_amd.dist import HostRehearsalComm
+    c = HostRehearsalComm(None, rank, world, tag, directory=directory)
+    got = c.exchange(np.arange(4.0) + 10.0 * rank)
+    tim = c.allgather_host([1.5 + rank])
+    c.barrier()
+    q.put((rank, [g.tolist() for g in got], tim.tolist()))
+
+
+def test_host_rehearsal_comm_exchanges_between_processes(tmp_path):
+    """The file transport that rehearses bench.py --gpus N on a one-GPU box (HMG_COMM=host-rehearsal):
+    three processes, every rank receives every rank's array in rank order, several rounds."""
+    import multiprocessing as mp
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    # same parent for all ranks, as under the launcher (the file names carry the parent's PID)
+    procs = [ctx.Process(target=_rehearsal_rank, args=(r, world, "t", str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, tim in res:
+        assert got == [[0.0, 1.0, 2.0, 3.0], [10.0, 11.0, 12.0, 13.0], [20.0, 21.0, 22.0, 23.0]]
+        assert tim == [[1.5], [2.5], [3.5]]
