@@ -1845,7 +1845,9 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs
 #pragma unroll
                 for (int b = a; b < NTR; ++b) {
                     if (A.P1h[p]) A.P1h[p][o] = acc[NTR + p][v] * damp;
-                    if (A.P2h[p]) A.P2h[p][o] = plin * (acc[a][v] + bmc[a]) * (acc[b][v] + bmc[b]);
+                    // (the two brackets are multiplied first: commutative, so the result does not depend on
+                    // which of the two tracers got the lower index in this batch)
+                    if (A.P2h[p]) A.P2h[p][o] = plin * ((acc[a][v] + bmc[a]) * (acc[b][v] + bmc[b]));
                     ++p;
                 }
             }

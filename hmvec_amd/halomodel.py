@@ -893,7 +893,12 @@ class HaloModel(Cosmology):
         if ent is not None and ent[0] == self._version:
             return ent[1], ent[2]
         pairs = self._free_riders(name, name2)
-        if pairs and ((name, name2) in pairs or (name2, name) in pairs) and len(pairs) > 1:
+        # Batchable requests always go through the batched kernel, also when nothing rides along: a pair's
+        # sums do not depend on what else is in the batch (foreign tensors enter with exact-zero coefficients),
+        # so a spectrum has the same bits whatever was asked for before it.  The one-pair kernel (another
+        # summation order, ~1e-16 away) is left with what the batch cannot do: bias overrides, the verbose
+        # terms, names the 1-halo and 2-halo lookups resolve differently, two different HOD/pressure names.
+        if pairs and ((name, name2) in pairs or (name2, name) in pairs):
             o1, o2 = self.power_device_batch(pairs)
             for (a, b), d1, d2 in zip(pairs, o1, o2):
                 self._pcache[(a, b)] = (self._version, d1, d2)

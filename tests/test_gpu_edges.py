@@ -408,3 +408,33 @@ def test_constructor_stage_in_one_launch_equals_the_two_launches(nz, nm, monkeyp
     for name in ("m200c", "r200c"):
         assert np.array_equal(one._buf(name, (nz, nm)).numpy(), two._buf(name, (nz, nm)).numpy()), name
     assert np.array_equal(one.uk_profiles["nfw"], two.uk_profiles["nfw"])
+
+
+def test_a_spectrum_does_not_depend_on_what_was_asked_before():
+    """get_power(a,b) comes from the batched kernel whether or not other pairs ride along, and a pair's
+    sums do not depend on the rest of the batch: the same bits for every call history."""
+    import hmvec_amd as hm
+    zs = np.linspace(0.2, 2.0, 5)
+    ms = np.geomspace(1e11, 1e16, 70)
+    ks = np.geomspace(1e-3, 30, 150)
+
+    def model():
+        h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+        h.add_battaglia_profile("electron", nxs=400, xmax=20)
+        h.add_battaglia_pres_profile("y", nxs=400, xmax=20)
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+        return h
+
+    pairs = [("electron", "electron"), ("nfw", "nfw"), ("g", "g"), ("g", "electron"), ("nfw", "electron"),
+             ("y", "y"), ("g", "y")]
+    a = model()
+    first = {p: (a.get_power_1halo(*p), a.get_power_2halo(*p)) for p in pairs}
+    b = model()
+    for p in reversed(pairs):                       # other order: other batches, other free riders
+        one, two = b.get_power_1halo(*p), b.get_power_2halo(*p)
+        assert np.array_equal(one, first[p][0]) and np.array_equal(two, first[p][1]), p
+    c = model()
+    blk = c.spectra_block(pairs[:5])                # and the explicit batch of bench.py / ShardedSpectra
+    blk.compute()
+    for p, (one, two) in blk.fetch().items():
+        assert np.array_equal(one, first[p][0]) and np.array_equal(two, first[p][1]), p
