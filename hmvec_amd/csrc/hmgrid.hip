@@ -99,6 +99,13 @@ struct hmg_ctx {
     double* d_barrier = nullptr;
     hmg::SiciTable* d_sici = nullptr;  // Si/Ci coefficients, read through the scalar cache
     void* pinned[2] = {nullptr, nullptr};   // host bounce buffers for pageable <-> device copies
+    // small host -> device copies: a ring of pinned slots, so that an upload is a memcpy + an asynchronous DMA
+    // and the host does not wait for the stream (a model's constructor makes ~20 of these)
+    static constexpr int UP_SLOTS = 32;
+    static constexpr size_t UP_SLOT_BYTES = (size_t)256 << 10;
+    char* up_ring = nullptr;
+    hipEvent_t up_ev[UP_SLOTS] = {};
+    int up_next = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     int num_cu = 256;
     // device blocks handed back by hmg_free, kept for reuse by size: dropping an array never
@@ -2228,6 +2235,10 @@ int hmg_ctx_destroy(hmg_ctx* c) {
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     if (c->d_barrier) (void)hipFree(c->d_barrier);
     if (c->d_sici) (void)hipFree(c->d_sici);
+    if (c->up_ring) {
+        (void)hipHostFree(c->up_ring);
+        for (auto& e : c->up_ev) if (e) (void)hipEventDestroy(e);
+    }
     for (int i = 0; i < 2; ++i) {
         if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
@@ -2316,6 +2327,25 @@ static int ensure_pinned(hmg_ctx* c) {
 // pinned 8 MiB buffers (DMA of chunk i+1 overlapped with the host memcpy of chunk i) is 5-8x faster.
 int hmg_memcpy_h2d(hmg_ctx* c, void* d, const void* h, size_t bytes) {
     REQUIRE(c && d && h, "NULL argument");
+    if (bytes <= hmg_ctx::UP_SLOT_BYTES && !c->capturing && !c->lanes_dirty && c->stream == c->lanes[0]) {
+        // the caller's array is copied into a pinned slot now, the DMA out of the slot is stream-ordered: no
+        // host wait (a slot is reused only after its own DMA has finished).  Only while everything runs on
+        // lane 0: with other lanes in play the consumer may sit on another stream, and the synchronous path
+        // below is what orders it
+        if (!c->up_ring) {
+            HIP_TRY(hipHostMalloc((void**)&c->up_ring, hmg_ctx::UP_SLOTS * hmg_ctx::UP_SLOT_BYTES, hipHostMallocDefault));
+            for (int i = 0; i < hmg_ctx::UP_SLOTS; ++i)
+                HIP_TRY(hipEventCreateWithFlags(&c->up_ev[i], hipEventDisableTiming));
+        }
+        const int slot = c->up_next;
+        c->up_next = (c->up_next + 1) % hmg_ctx::UP_SLOTS;
+        HIP_TRY(hipEventSynchronize(c->up_ev[slot]));
+        char* stage = c->up_ring + (size_t)slot * hmg_ctx::UP_SLOT_BYTES;
+        memcpy(stage, h, bytes);
+        HIP_TRY(hipMemcpyAsync(d, stage, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->up_ev[slot], c->stream));
+        return 0;
+    }
     if (bytes < (256u << 10)) {
         HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
