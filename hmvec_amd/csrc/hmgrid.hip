@@ -1579,10 +1579,47 @@ __global__ __launch_bounds__(1024) void power_kernel(PowerArgs A) {
 constexpr int PB_MAXTR = 4;
 constexpr int PB_MAXPAIR = PB_MAXTR * (PB_MAXTR + 1) / 2;
 
+// Structure of a batch.  Most coefficients of the generic linear forms are structural zeros or ones:
+//   matter / pressure on tensor s   ("LIN s"):  W = A1 = A2 = c t_s                          1 number per (z,m)
+//   HOD, satellites on s, u_c == 1  ("HOD s"):  W = c0 + c1 t_s, A1 = t_s, A2 = a0 + a1 t_s  4 numbers
+// For the batches the facade issues most (PB_SPEC_LIST) the kernel is compiled for that structure: a row of
+// 2 + sum numbers instead of 2 + 3 NTR (1+NT), padded to whole 64-byte lines - Config 3: 8 doubles, one
+// s_load_dwordx16, against 29 - and only the non-zero terms are evaluated, with the operations the generic
+// forms apply to them (adding an exact zero or multiplying by an exact one changes no bit), so both paths
+// give the same sums.  What the mass loop cannot afford is scalar-memory traffic per bin.
+// A code packs 4 bits per tracer, tracer 0 lowest: bits 0-1 kind (0 none, 1 LIN, 2 HOD), bits 2-3 tensor slot.
+constexpr unsigned PB_LIN(int s) { return 1u | ((unsigned)s << 2); }
+constexpr unsigned PB_HOD(int s) { return 2u | ((unsigned)s << 2); }
+constexpr unsigned pb_code(unsigned t0, unsigned t1 = 0, unsigned t2 = 0, unsigned t3 = 0) {
+    return t0 | (t1 << 4) | (t2 << 8) | (t3 << 12);
+}
+constexpr int pb_kind(unsigned code, int r) { return (int)((code >> (4 * r)) & 3u); }
+constexpr int pb_slot(unsigned code, int r) { return (int)((code >> (4 * r + 2)) & 3u); }
+constexpr int pb_ncoef(unsigned code, int ntr) {     // numbers per compact row before padding
+    int n = 2;
+    for (int r = 0; r < ntr; ++r) n += pb_kind(code, r) == 2 ? 4 : 1;
+    return n;
+}
+constexpr int pb_stride(unsigned code, int ntr, int nc1) {   // doubles per (z,m) coefficient row
+    return code ? ((pb_ncoef(code, ntr) + 7) & ~7) : 2 + ntr * 3 * nc1;
+}
+
+// (distinct tensors, tracers, structure) the kernel is compiled for: what get_power*/spectra_block produce for
+// matter and pressure profiles and an HOD whose satellites follow the first matter profile (the reference's
+// README usage: 'nfw', a Battaglia gas profile, a pressure profile, an HOD)
+#define PB_SPEC_LIST                                                  \
+    PB_SPEC(1, 1, PB_LIN(0))                                          \
+    PB_SPEC(1, 2, PB_LIN(0), PB_HOD(0))                               \
+    PB_SPEC(2, 2, PB_LIN(0), PB_LIN(1))                               \
+    PB_SPEC(2, 3, PB_LIN(0), PB_LIN(1), PB_HOD(0))                    \
+    PB_SPEC(3, 3, PB_LIN(0), PB_LIN(1), PB_LIN(2))                    \
+    PB_SPEC(3, 4, PB_LIN(0), PB_LIN(1), PB_LIN(2), PB_HOD(0))
+
 struct BatchPrep {
     TracerDev tr[PB_MAXTR];
     int ntr, nt;
     double rho_m0;
+    unsigned code;       // 0: generic rows; else the compact rows of that structure
 };
 
 // coef layout per (z,m): [wn, wnb, {W[1+nt], A1[1+nt], A2[1+nt]} x ntr].
@@ -1599,7 +1636,7 @@ __global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep 
     const int z = blockIdx.x, blk = blockIdx.y, nblk = gridDim.y;
     const int m = blk * 64 + threadIdx.x;
     const int nc1 = 1 + Q.nt;
-    const int stride = 2 + Q.ntr * 3 * nc1;
+    const int stride = pb_stride(Q.code, Q.ntr, nc1);
     double accC[PB_MAXTR], accB[PB_MAXTR];
     for (int t = 0; t < PB_MAXTR; ++t) accC[t] = accB[t] = 0.0;
     if (m < nm) {
@@ -1610,6 +1647,7 @@ __global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep 
         double* c = coef + idx * (size_t)stride;
         c[0] = wn;
         c[1] = wnb;
+        int pos = 2;
         for (int t = 0; t < Q.ntr; ++t) {
             const TracerDev& T = Q.tr[t];
             double w[1 + PW_MAXT], a1[1 + PW_MAXT], a2[1 + PW_MAXT], low;
@@ -1624,14 +1662,24 @@ __global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep 
                 a2[1 + T.t_prof] += T.NsNsm1[idx] / ng2;
                 accB[t] = wnb * (T.Nc[idx] + T.Ns[idx]);
             }
-            double* ct = c + 2 + t * 3 * nc1;
-            for (int i = 0; i < nc1; ++i) {
-                ct[i] = w[i];
-                ct[nc1 + i] = a1[i];
-                ct[2 * nc1 + i] = a2[i];
+            if (Q.code == 0) {
+                double* ct = c + 2 + t * 3 * nc1;
+                for (int i = 0; i < nc1; ++i) {
+                    ct[i] = w[i];
+                    ct[nc1 + i] = a1[i];
+                    ct[2 * nc1 + i] = a2[i];
+                }
+            } else {                  // compact row: only the numbers that are not structural zeros / ones
+                const int sl = 1 + pb_slot(Q.code, t);
+                if (pb_kind(Q.code, t) == 1) {
+                    c[pos++] = w[sl];
+                } else {
+                    c[pos++] = w[0]; c[pos++] = w[sl]; c[pos++] = a2[0]; c[pos++] = a2[sl];
+                }
             }
             accC[t] = wnb * low;
         }
+        if (Q.code) for (; pos < stride; ++pos) c[pos] = 0.0;
     }
     for (int t = 0; t < Q.ntr; ++t) {
         const double C = wave_sum(accC[t]);
@@ -1671,12 +1719,12 @@ struct BatchArgs {
 //                which is what a thin z-slab (one workgroup per CU) needs.
 constexpr int PB_NV = 16;
 
-template <int NT, int NTR, int V, bool W16>
+template <int NT, int NTR, int V, bool W16, unsigned CODE = 0>
 __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs A) {
     extern __shared__ double red[];  // [8][NACC*V][64]: parked sums / pair exchange, then the cross-wave reduction
     using vec_t = typename VecT<V>::type;
     constexpr int NC1 = 1 + NT;
-    constexpr int STRIDE = 2 + NTR * 3 * NC1;
+    constexpr int STRIDE = pb_stride(CODE, NTR, NC1);
     constexpr int NPAIR = NTR * (NTR + 1) / 2;
     constexpr int NACC = NTR + NPAIR;
     const int lane = threadIdx.x & 63;
@@ -1736,6 +1784,25 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             double W[NTR], A1[NTR], A2[NTR];
+            if constexpr (CODE != 0) {
+                // compiled for this batch's structure: only the non-zero terms of the forms
+                int pos = 2;
+#pragma unroll
+                for (int r = 0; r < NTR; ++r) {
+                    const double ts = vget<V>(t[pb_slot(CODE, r)], v);
+                    if (pb_kind(CODE, r) == 1) {          // (constant after unrolling)
+                        W[r] = c[pos] * ts;
+                        A1[r] = W[r]; A2[r] = W[r];
+                        pos += 1;
+                    } else {
+                        W[r] = fma(c[pos + 1], ts, c[pos]);
+                        A1[r] = ts;
+                        A2[r] = fma(c[pos + 3], ts, c[pos + 2]);
+                        pos += 4;
+                    }
+                    acc[r][v] += wnb * W[r];
+                }
+            } else
 #pragma unroll
             for (int r = 0; r < NTR; ++r) {
                 const double* cr = c + 2 + r * 3 * NC1;
@@ -3059,31 +3126,49 @@ int hmg_power_2halo_terms(hmg_ctx* c, int nz, int nm, int nk, const hmg_tracer* 
     return power_impl(c, nz, nm, nk, ta, tb, nzm, bh, ms, wm, ks, nullptr, rho_m0, 1.0, nullptr, nullptr, I1, I2, C12);
 }
 
-template <int NT, int NTR, int V, bool W16>
+template <int NT, int NTR, int V, bool W16, unsigned CODE = 0>
 static int launch_power_batch(hmg_ctx* c, const BatchArgs& A, int nz) {
     const int per_block = 64 * V;
     dim3 grid((A.nk + per_block - 1) / per_block, nz);
     constexpr int NACC = NTR + NTR * (NTR + 1) / 2;
     const size_t lds = (size_t)8 * NACC * V * 64 * sizeof(double);
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)power_batch_kernel<NT, NTR, V, W16>,
+        HIP_TRY(hipFuncSetAttribute((const void*)power_batch_kernel<NT, NTR, V, W16, CODE>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int stop = -1;
     if (bracket_open(c, HMG_KERNEL_POWER, &stop)) return 1;
-    hipLaunchKernelGGL((power_batch_kernel<NT, NTR, V, W16>), grid, dim3(W16 ? 1024 : 512), lds, c->stream, A);
+    hipLaunchKernelGGL((power_batch_kernel<NT, NTR, V, W16, CODE>), grid, dim3(W16 ? 1024 : 512), lds, c->stream, A);
     HIP_TRY(hipGetLastError());
     return bracket_close(c, stop);
 }
 
-int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_tracer* tr, int npairs,
+int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_tracer* tr_in, int npairs,
                     const int* pair_a, const int* pair_b, const double* nzm, const double* bh,
                     const double* ms, const double* wm, const double* ks, const double* Pzk,
                     double rho_m0, double kstar, double* const* P1h, double* const* P2h) {
-    REQUIRE(c && tr && pair_a && pair_b && nzm && bh && ms && wm && ks, "NULL argument");
+    REQUIRE(c && tr_in && pair_a && pair_b && nzm && bh && ms && wm && ks, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
     REQUIRE(nz <= 65535, "nz too large");
     REQUIRE(ntr >= 1 && ntr <= PB_MAXTR, "1..4 tracers per batch");
     REQUIRE(npairs >= 1, "no pairs");
+    // Canonical tracer order: matter / pressure tracers first - those whose tensor an HOD of the batch uses for its
+    // satellites before the others -, HOD tracers after them, each group in the caller's order.  A pair's sums do not depend on the tracers' order in the batch (the forms of a tracer involve only
+    // its own tensors; the two 2-halo brackets are multiplied before P_lin), so this changes no result - it
+    // only makes batches of the same structure look the same to the dispatch below.
+    hmg_tracer tr[PB_MAXTR];
+    int where[PB_MAXTR];
+    {
+        auto group = [&](int t) {
+            if (tr_in[t].kind == HMG_TRACER_HOD) return 2;
+            for (int u = 0; u < ntr; ++u)
+                if (tr_in[u].kind == HMG_TRACER_HOD && tr_in[u].d_prof == tr_in[t].d_prof) return 0;
+            return 1;
+        };
+        int n = 0;
+        for (int pass = 0; pass < 3; ++pass)
+            for (int t = 0; t < ntr; ++t)
+                if (group(t) == pass) { tr[n] = tr_in[t]; where[t] = n++; }
+    }
     std::vector<const double*> tens;
     BatchPrep Q;
     for (int t = 0; t < ntr; ++t) {
@@ -3094,12 +3179,20 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     Q.nt = (int)tens.size();
     Q.rho_m0 = rho_m0;
     REQUIRE(Q.nt >= 1 && Q.nt <= PW_MAXT, "more than 4 distinct profile tensors in one batch");
+    // structure code of the batch (0 if a tracer has no compact form: an HOD with a central profile)
+    unsigned code = 0;
+    for (int t = 0; t < ntr; ++t) {
+        const bool hod = Q.tr[t].kind == HMG_TRACER_HOD;
+        if (hod && Q.tr[t].t_cprof >= 0) { code = 0; break; }
+        code |= (hod ? PB_HOD(Q.tr[t].t_prof) : PB_LIN(Q.tr[t].t_prof)) << (4 * t);
+    }
+    if (getenv("HMG_PB_GENERIC")) code = 0;            // (testing: the generic forms for every batch)
     BatchArgs A;
     for (int p = 0; p < PB_MAXPAIR; ++p) A.P1h[p] = A.P2h[p] = nullptr;
     bool any2 = false;
     for (int i = 0; i < npairs; ++i) {
-        int a = pair_a[i], b = pair_b[i];
-        REQUIRE(a >= 0 && a < ntr && b >= 0 && b < ntr, "pair index out of range");
+        REQUIRE(pair_a[i] >= 0 && pair_a[i] < ntr && pair_b[i] >= 0 && pair_b[i] < ntr, "pair index out of range");
+        int a = where[pair_a[i]], b = where[pair_b[i]];
         if (a > b) { int t = a; a = b; b = t; }
         const int p = a * ntr - a * (a - 1) / 2 + (b - a);
         REQUIRE((P1h && P1h[i]) || (P2h && P2h[i]), "pair without output");
@@ -3108,8 +3201,18 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
         if (P2h && P2h[i]) { A.P2h[p] = P2h[i]; any2 = true; }
     }
     REQUIRE(!any2 || Pzk, "P2h needs Pzk");
+    // the structures the kernel is compiled for; anything else runs the generic forms
+    static const struct { int nt, ntr; unsigned code; } spec_list[] = {
+#define PB_SPEC(NT_, NTR_, ...) {NT_, NTR_, pb_code(__VA_ARGS__)},
+        PB_SPEC_LIST
+#undef PB_SPEC
+    };
+    bool compiled = false;
+    for (const auto& e : spec_list) compiled = compiled || (e.nt == Q.nt && e.ntr == ntr && e.code == code);
+    if (!compiled) code = 0;
+    Q.code = code;
     const int nc1 = 1 + Q.nt;
-    const int stride = 2 + ntr * 3 * nc1;
+    const int stride = pb_stride(code, ntr, nc1);
     const int nblk = (nm + 63) / 64;
     REQUIRE(nblk <= 65535, "nm too large");
     if (ensure_scratch(c, 3, (size_t)nz * nm * stride * 8 + (size_t)nz * nblk * ntr * 2 * 8 + 64)) return 1;
@@ -3149,11 +3252,18 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     if (const char* e = getenv("HMG_PB_THIN")) thin = atoi(e);      // tuning/testing: force a shape (2: V=1, 8 wavefronts)
     if (thin == 3 && !vec2) thin = 1;
     if (thin == 1 || thin == 2) vec2 = false;
-#define PB_V(NT_, NTR_)                                                              \
-    if (thin == 3) return launch_power_batch<NT_, NTR_, 2, true>(c, A, nz);          \
-    return thin == 1 ? launch_power_batch<NT_, NTR_, 1, true>(c, A, nz)              \
-                     : (vec2 ? launch_power_batch<NT_, NTR_, 2, false>(c, A, nz)     \
-                             : launch_power_batch<NT_, NTR_, 1, false>(c, A, nz));
+#define PB_SHAPES(NT_, NTR_, CODE_)                                                        \
+    if (thin == 3) return launch_power_batch<NT_, NTR_, 2, true, CODE_>(c, A, nz);         \
+    return thin == 1 ? launch_power_batch<NT_, NTR_, 1, true, CODE_>(c, A, nz)             \
+                     : (vec2 ? launch_power_batch<NT_, NTR_, 2, false, CODE_>(c, A, nz)    \
+                             : launch_power_batch<NT_, NTR_, 1, false, CODE_>(c, A, nz));
+    if (code) {
+#define PB_SPEC(NT_, NTR_, ...)                                                            \
+        if (Q.nt == NT_ && ntr == NTR_ && code == pb_code(__VA_ARGS__)) { PB_SHAPES(NT_, NTR_, pb_code(__VA_ARGS__)) }
+        PB_SPEC_LIST
+#undef PB_SPEC
+    }
+#define PB_V(NT_, NTR_) PB_SHAPES(NT_, NTR_, 0u)
 #define PB_NTR(NT_)                         \
     switch (ntr) {                          \
         case 1: PB_V(NT_, 1)                \
@@ -3170,6 +3280,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     }
 #undef PB_NTR
 #undef PB_V
+#undef PB_SHAPES
     return fail("hmg_power_batch", "unreachable", __FILE__, __LINE__);
 }
 

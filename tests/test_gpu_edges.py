@@ -438,3 +438,39 @@ def test_a_spectrum_does_not_depend_on_what_was_asked_before():
     blk.compute()
     for p, (one, two) in blk.fetch().items():
         assert np.array_equal(one, first[p][0]) and np.array_equal(two, first[p][1]), p
+
+
+def test_structure_compiled_mass_integrals_equal_the_generic_forms(monkeypatch):
+    """hmg_power_batch runs a kernel compiled for the batch's structure (which coefficients of the linear
+    forms are structural zeros or ones) where it has one, the generic forms otherwise (HMG_PB_GENERIC=1
+    forces them): the same sums bit for bit, for every batch the facade issues here - one to four tracers,
+    one to three tensors, tracers in any order, every launch shape."""
+    import hmvec_amd as hm
+    zs = np.linspace(0.2, 2.0, 3)
+    ms = np.geomspace(1e11, 1e16, 70)
+    ks = np.geomspace(1e-3, 30, 130)
+
+    def model():
+        h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+        h.add_battaglia_profile("electron", nxs=400, xmax=20)
+        h.add_battaglia_pres_profile("y", nxs=400, xmax=20)
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+        h.add_hod("gc", mthresh=10 ** 10.8 + zs * 0.0, central_profile_name="electron")   # no compact form
+        return h
+
+    batches = [[("nfw", "nfw")], [("electron", "electron")], [("nfw", "nfw"), ("g", "g"), ("g", "nfw")],
+               [("electron", "nfw"), ("nfw", "nfw")], [("g", "electron"), ("electron", "electron"), ("nfw", "g")],
+               [("y", "y"), ("nfw", "y"), ("electron", "y")], [("g", "y"), ("y", "electron"), ("nfw", "nfw"), ("g", "g")],
+               [("gc", "gc"), ("gc", "nfw")]]
+    for thin in ("0", "1", "3"):
+        monkeypatch.setenv("HMG_PB_THIN", thin)
+        for pairs in batches:
+            monkeypatch.delenv("HMG_PB_GENERIC", raising=False)
+            a = model().spectra_block(pairs)
+            a.compute()
+            got = {p: (x.copy(), y.copy()) for p, (x, y) in a.fetch().items()}
+            monkeypatch.setenv("HMG_PB_GENERIC", "1")
+            b = model().spectra_block(pairs)
+            b.compute()
+            for p, (x, y) in b.fetch().items():
+                assert np.array_equal(got[p][0], x) and np.array_equal(got[p][1], y), (thin, pairs, p)
