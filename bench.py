@@ -227,7 +227,8 @@ def power_bytes_moved(nzl, nm, nk, npair, nconst, vec):
     widths = np.diff(np.concatenate([[0], ends]))
     read = (nconst.reshape(-1, 1) < ends[None, :]) * widths[None, :]
     tens = 8.0 * nzl * nm * nk + 8.0 * float(read.sum())
-    stride = 2 + 3 * 3 * 3                        # coefficient doubles per (z,m): hmgrid.hip power_batch_prep
+    stride = 8                                    # coefficient doubles per (z,m): the compact rows of this batch's
+                                                  # structure (hmgrid.hip pb_stride; the generic forms take 29)
     side = 8.0 * nzl * nm * (stride + 2)          # coefficient rows + hint count/value
     outs = 8.0 * nzl * nk * (2 * npair + 1)       # spectra + P_lin
     return tens + side + outs, tens
