@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -52,6 +52,57 @@ class Tracer(C.Structure):
                 ("d_cprof_nconst", C.c_void_p), ("d_cprof_cconst", C.c_void_p)]
 
 
+class MassFnPart(C.Structure):
+    """hmg_massfn_part: second stage of the sigma^2 contraction + n(z,m), b(z,m) as a link of a per-z chain."""
+    _fields_ = [("h_par", C.POINTER(MassFnParams)), ("d_ms", C.c_void_p), ("d_lnms", C.c_void_p),
+                ("d_tinker_z", C.c_void_p), ("d_sigma2", C.c_void_p), ("d_nzm", C.c_void_p), ("d_bh", C.c_void_p)]
+
+
+class HodPart(C.Structure):
+    """hmg_hod_part: hmg_hod's arguments."""
+    _fields_ = [("stage", C.c_int), ("h_par", C.POINTER(HodParams)), ("d_zs", C.c_void_p), ("d_ms", C.c_void_p),
+                ("d_log10mstar_thresh", C.c_void_p), ("d_nzm", C.c_void_p), ("d_bh", C.c_void_p),
+                ("d_wm", C.c_void_p), ("d_Nc", C.c_void_p), ("d_Ns", C.c_void_p), ("d_NsNsm1", C.c_void_p),
+                ("d_NcNs", C.c_void_p), ("d_ngal", C.c_void_p), ("d_bg", C.c_void_p)]
+
+
+class RowsPart(C.Structure):
+    """hmg_rows_part: hmg_profile_rowparams's arguments."""
+    _fields_ = [("kind", C.c_int), ("d_m200c", C.c_void_p), ("d_r200c", C.c_void_p), ("d_rvir", C.c_void_p),
+                ("d_zs", C.c_void_p), ("d_rhocz", C.c_void_p), ("d_hz", C.c_void_p), ("fit", C.c_double * 9),
+                ("gamma", C.c_double), ("alpha_const", C.c_double), ("amp_prefactor", C.c_double),
+                ("post_prefactor", C.c_double), ("d_amp", C.c_void_p), ("d_xc", C.c_void_p),
+                ("d_alpha", C.c_void_p), ("d_expo", C.c_void_p), ("d_cmax", C.c_void_p),
+                ("d_rscale", C.c_void_p), ("d_post", C.c_void_p)]
+
+
+class NfwPart(C.Structure):
+    """hmg_nfw_part: hmg_nfw_analytic's arguments."""
+    _fields_ = [("d_cs", C.c_void_p), ("d_rs", C.c_void_p), ("d_zs", C.c_void_p), ("d_ks", C.c_void_p),
+                ("d_nfw_series", C.c_void_p), ("d_uk", C.c_void_p)]
+
+
+class ProfileFftPart(C.Structure):
+    """hmg_profile_fft_part: hmg_profile_fft's arguments after nk."""
+    _fields_ = [("nxs", C.c_int), ("fft_step", C.c_double), ("d_xs", C.c_void_p), ("d_kts", C.c_void_p),
+                ("d_amp", C.c_void_p), ("d_xc", C.c_void_p), ("d_alpha", C.c_void_p), ("d_expo", C.c_void_p),
+                ("amp_const", C.c_double), ("xc_const", C.c_double), ("alpha_const", C.c_double),
+                ("expo_const", C.c_double), ("gamma", C.c_double), ("d_cmax", C.c_void_p), ("d_rss", C.c_void_p),
+                ("d_zs", C.c_void_p), ("d_ks", C.c_void_p), ("do_mass_norm", C.c_int), ("d_post", C.c_void_p),
+                ("d_out", C.c_void_p), ("d_nconst", C.c_void_p), ("d_cconst", C.c_void_p), ("d_logxs", C.c_void_p)]
+
+
+class PowerBatchDesc(C.Structure):
+    """hmg_power_batch_desc: hmg_power_batch's arguments after nk."""
+    _fields_ = [("ntr", C.c_int), ("h_tr", C.POINTER(Tracer)), ("npairs", C.c_int),
+                ("h_pair_a", C.POINTER(C.c_int)), ("h_pair_b", C.POINTER(C.c_int)),
+                ("d_nzm", C.c_void_p), ("d_bh", C.c_void_p), ("d_ms", C.c_void_p), ("d_wm", C.c_void_p),
+                ("d_ks", C.c_void_p), ("d_Pzk", C.c_void_p), ("rho_m0", C.c_double), ("kstar", C.c_double),
+                ("h_P1h", C.POINTER(C.c_void_p)), ("h_P2h", C.POINTER(C.c_void_p))]
+
+
+PB_PREPARED = 1
+HOD_ALL, HOD_OCCUPATIONS, HOD_SUMS = 0, 1, 2
 MF_SHETH_TORMEN, MF_TINKER10 = 0, 1
 PROF_BATTAGLIA_GAS, PROF_BATTAGLIA_PRES = 1, 2
 TRACER_MATTER, TRACER_HOD, TRACER_PRESSURE = 0, 1, 2
@@ -110,6 +161,11 @@ SIGNATURES = {
                         _P, _P, _P, _P, _P, _P, _D, _D, C.POINTER(_P), C.POINTER(_P)],
     "hmg_power_2halo_terms": [_P, _I, _I, _I, C.POINTER(Tracer), C.POINTER(Tracer), _P, _P, _P, _P, _P, _D,
                               _P, _P, _P],
+    "hmg_sigma2_halo_front": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P, C.POINTER(HaloStageArgs), C.POINTER(HodPart)],
+    "hmg_group_rows": [_P, _I, _I, _I, _I, C.POINTER(MassFnPart), C.POINTER(HodPart), C.POINTER(RowsPart),
+                       C.POINTER(NfwPart)],
+    "hmg_group_profile": [_P, _I, _I, _I, C.POINTER(ProfileFftPart), C.POINTER(HodPart), C.POINTER(PowerBatchDesc)],
+    "hmg_power_batch_run": [_P, _I, _I, _I, C.POINTER(PowerBatchDesc), _I],
     "hmg_limber": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "hmg_fn2d": [_P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_D), _I, _P],
     "hmg_mstellar_halo": [_P, _I, _I, _P, _P, _P],
@@ -176,6 +232,7 @@ class DeviceArray:
         return self.size * 8
 
     def numpy(self):
+        self.ctx.flush()
         out = np.empty(self.shape, dtype=np.float64)
         check(self.ctx.lib.hmg_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
         return out
@@ -234,6 +291,22 @@ class Context:
         self.handle = h.value
         self.device = int(device)
         self.capture_serial = 0       # changes at every capture begin/end: events recorded before are off limits
+        self._deferred = []           # objects with stages queued for a grouped launch (HaloModel), in order
+
+    # deferred stages: a HaloModel queues the launch-only stages of a pass so that independent ones can
+    # share a launch (hmg_group_*); ANY other native call of this context issues them first, so program
+    # order is what every consumer sees
+    def defer(self, owner):
+        if owner not in self._deferred:
+            self._deferred.append(owner)
+
+    def flush(self):
+        while self._deferred:
+            self._deferred.pop(0)._flush()
+
+    def call_now(self, name, *args):
+        """A native call that does not flush the deferred stages (used while they are being issued)."""
+        check(getattr(self.lib, name)(self.handle, *args))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -256,27 +329,38 @@ class Context:
 
     def upload(self, arr):
         a = np.ascontiguousarray(arr, dtype=np.float64)
-        d = self.empty(a.shape)
+        d = self.empty(a.shape)          # a fresh block: no queued stage can refer to it
         check(self.lib.hmg_memcpy_h2d(self.handle, d.ptr, a.ctypes.data, a.nbytes))
         return d
 
+    def write(self, dst, arr):
+        """Overwrite DeviceArray ``dst`` with a host array (stream-ordered behind everything queued so far)."""
+        self.flush()
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        check(self.lib.hmg_memcpy_h2d(self.handle, dst.ptr, a.ctypes.data, a.nbytes))
+
     def copy(self, src):
+        self.flush()
         d = self.empty(src.shape)
         check(self.lib.hmg_memcpy_d2d(self.handle, d.ptr, src.ptr, src.nbytes))
         return d
 
     def sync(self):
+        self.flush()
         check(self.lib.hmg_sync(self.handle))
 
     def record(self, slot):
+        self.flush()
         check(self.lib.hmg_event_record(self.handle, slot))
 
     def lane(self, i):
         """Route subsequent launches to lane i (0 = main stream)."""
+        self.flush()
         check(self.lib.hmg_lane_set(self.handle, i))
 
     def wait(self, slot):
         """Current lane waits for the event last recorded in `slot`."""
+        self.flush()
         check(self.lib.hmg_event_wait(self.handle, slot))
 
     def elapsed_ms(self, s0, s1):
@@ -284,18 +368,27 @@ class Context:
         check(self.lib.hmg_elapsed_ms(self.handle, s0, s1, C.byref(ms)))
         return ms.value
 
+    _NO_FLUSH = frozenset(["hmg_bracket_next"])      # calls that enqueue nothing and read nothing
+
     def call(self, name, *args):
+        if name not in self._NO_FLUSH:
+            self.flush()
         check(getattr(self.lib, name)(self.handle, *args))
 
     # captured steps
     def capture(self, fn):
         """Run ``fn()`` (launch-only: no allocation, upload, download or synchronisation) inside a
         HIP-graph capture and return the graph id for ``replay``."""
+        self.flush()                      # stages queued before the capture are not part of it
         check(self.lib.hmg_graph_begin(self.handle))
         self.capture_serial += 1
         try:
             fn()
+            self.flush()                  # ... and those queued inside it are
         except BaseException:
+            for o in self._deferred:       # whatever was queued inside the failed capture is dropped with it
+                o._stages = []
+            self._deferred.clear()
             self.lib.hmg_graph_abort(self.handle)
             self.capture_serial += 1
             raise
@@ -307,10 +400,12 @@ class Context:
         return gid.value
 
     def replay(self, gid):
+        self.flush()
         check(self.lib.hmg_graph_launch(self.handle, gid))
 
     def copy_to_pinned(self, pinned, src):
         """Asynchronous D2H of DeviceArray ``src`` into PinnedArray ``pinned`` on the current lane."""
+        self.flush()
         check(self.lib.hmg_memcpy_d2h_async(self.handle, pinned.ptr, src.ptr, src.nbytes))
 
 

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +95,7 @@ struct hmg_ctx {
     std::map<int, struct FusedPlan> fused;          // nxs -> workgroup-FFT tables
     size_t fft_chunk_bytes = 0;                    // 0 = default
     int use_fused_fft = 1;                         // HMG_FUSED_FFT=0 forces the rocFFT path
+    int sig_nz = 0, sig_nm = 0, sig_nq = 0;        // shape of the partial sums the last sigma^2 contraction left in scratch[4]
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     double* d_barrier = nullptr;
@@ -251,16 +253,15 @@ __global__ void transpose_pad_kernel(int rows, int rows_pad, int cols, const dou
 #define HMG_SIG_OCC 1
 #endif
 template <int ZB>
-__global__ __launch_bounds__(64, HMG_SIG_OCC) void sigma2_mfma_kernel(int nz, int nzp, int nm, int nq,
-                                                         const double* __restrict__ PT /*[nq][nzp]*/,
-                                                         const double* __restrict__ kq,
-                                                         const double* __restrict__ wq,
-                                                         const double* __restrict__ R, double tswitch,
-                                                         double* __restrict__ partial /*[seg][nz][nm]*/) {
-    const int lane = threadIdx.x, col = lane & 15, kk = lane >> 4;
-    const int m = blockIdx.x * 16 + col;
-    const int seg = blockIdx.y;
-    const int z0 = blockIdx.z * (16 * ZB);
+__device__ __forceinline__ void sigma2_mfma_block(int bx, int seg, int bz, int nz, int nzp, int nm, int nq,
+                                                  const double* __restrict__ PT /*[nq][nzp]*/,
+                                                  const double* __restrict__ kq,
+                                                  const double* __restrict__ wq,
+                                                  const double* __restrict__ R, double tswitch,
+                                                  double* __restrict__ partial /*[seg][nz][nm]*/) {
+    const int lane = threadIdx.x & 63, col = lane & 15, kk = lane >> 4;
+    const int m = bx * 16 + col;
+    const int z0 = bz * (16 * ZB);
     const double r = R[min(m, nm - 1)];
     d4_t acc[ZB];
 #pragma unroll
@@ -329,6 +330,13 @@ __global__ __launch_bounds__(64, HMG_SIG_OCC) void sigma2_mfma_kernel(int nz, in
                 if (z < nz) partial[((size_t)seg * nz + z) * nm + m] = acc[b][rg];
             }
     }
+}
+template <int ZB>
+__global__ __launch_bounds__(64, HMG_SIG_OCC) void sigma2_mfma_kernel(int nz, int nzp, int nm, int nq,
+                                                         const double* __restrict__ PT, const double* __restrict__ kq,
+                                                         const double* __restrict__ wq, const double* __restrict__ R,
+                                                         double tswitch, double* __restrict__ partial) {
+    sigma2_mfma_block<ZB>(blockIdx.x, blockIdx.y, blockIdx.z, nz, nzp, nm, nq, PT, kq, wq, R, tswitch, partial);
 }
 
 __device__ __forceinline__ double sigma2_segment_sum(int n, int parts, const double* __restrict__ partial, size_t i, int w) {
@@ -484,6 +492,35 @@ __global__ __launch_bounds__(512) void sigma2_massfn_kernel(SigmaMassFnArgs A) {
     __shared__ double sig[66];
     sigma2_massfn_block(A, blockIdx.y, blockIdx.x * 64, red, sig);
 }
+// The same stage for a 256-thread workgroup (the form a grouped launch uses beside the NFW rows): a tile is
+// 62 masses plus its two stencil neighbours = 64 slots, one per lane, so that the four wavefronts take the
+// four interleaved part groups of all 64 slots and nobody walks the parts twice.  Every sigma2[z][m] is summed
+// exactly as above (group g = parts g, g+4, ... in order, then ((g0 + g1) + g2) + g3), so the results are the
+// same bit for bit.  red: 4 x 64 doubles of LDS, sig: 64.
+constexpr int MF_TILE = 62;
+__device__ __forceinline__ void sigma2_massfn_tile(const SigmaMassFnArgs& A, int z, int tile, double* red, double* sig) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nm = A.nm, n = A.nz * nm, m0 = tile * MF_TILE;
+    {   // slot `lane` <-> mass m0 - 1 + lane (clamped to the row)
+        const int m = min(max(m0 - 1 + lane, 0), nm - 1);
+        red[w * 64 + lane] = sigma2_segment_sum(n, A.parts, A.partial, (size_t)z * nm + m, w);
+    }
+    __syncthreads();
+    if (w == 0) {
+        const double v = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+        sig[lane] = v;
+        const int m = m0 - 1 + lane;
+        if (lane >= 1 && lane <= MF_TILE && m < nm) A.s2[(size_t)z * nm + m] = v;
+    }
+    __syncthreads();
+    const int m = m0 + (int)threadIdx.x;
+    if (threadIdx.x < MF_TILE && m < nm) {
+        double nn, bb;
+        massfn_point(A.P, z, m, nm, [&](int i) { return sig[i - m0 + 1]; }, A.ms, A.lnm, A.tz, nn, bb);
+        A.nzm[(size_t)z * nm + m] = nn;
+        A.bh[(size_t)z * nm + m] = bb;
+    }
+}
 
 // ---------------------------------------------------------------- A5: c(m,z), rvir(m,z)
 __global__ void halo_structure_kernel(int nz, int nm, const double* __restrict__ ms,
@@ -605,19 +642,28 @@ __global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, doubl
 #ifndef HMG_NFW_OCC
 #define HMG_NFW_OCC 6
 #endif
-__global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* __restrict__ T,
-                                                  const double* __restrict__ acoef, int ktile, int nm, int nk,
-                                                  const double* __restrict__ cs,
-                                                  const double* __restrict__ rss,
-                                                  const double* __restrict__ zs,
-                                                  const double* __restrict__ ks,
-                                                  double* __restrict__ uk) {
+struct NfwArgs {
+    const SiciTable* T;
+    const double* acoef;
+    int ktile, nm, nk;
+    const double *cs, *rss, *zs, *ks;
+    double* uk;
+};
+// blk: index of the (row, k tile) this workgroup owns; nthr: threads that share it (the workgroup size).
+// The pointers must reach this function as __restrict__ KERNEL PARAMETERS (not as fields of a by-value
+// struct): only then can hipcc prove that the stores to uk do not clobber the row constants, series
+// coefficients and Si/Ci tables and fetch those with scalar loads - as struct fields they became 249 vector
+// loads per thread and the kernel ran 2.6x slower (0.15 -> 0.40 ms at Config 3).
+__device__ __forceinline__ void nfw_rows(const SiciTable* __restrict__ T, const double* __restrict__ acoef, int ktile,
+                                         int nm, int nk, const double* __restrict__ cs,
+                                         const double* __restrict__ rss, const double* __restrict__ zs,
+                                         const double* __restrict__ ks, double* __restrict__ uk, int blk, int nthr) {
     // one (z,m) row per workgroup, the whole k axis in one tile: measured against two rows per workgroup
     // (+4 %), half tiles (+40 %) and 128 threads per row (+-0): a workgroup's fixed cost is the latency of
     // its scalar loads (row constants, series coefficients), not instructions
     const int ktiles = (nk + ktile - 1) / ktile;
-    const int row = blockIdx.x / ktiles;  // z*nm + m
-    const int k_lo = (blockIdx.x - row * ktiles) * ktile;
+    const int row = blk / ktiles;  // z*nm + m
+    const int k_lo = (blk - row * ktiles) * ktile;
     const int k_hi = min(nk, k_lo + ktile);
     const int z = row / nm;
     const double c = cs[row];
@@ -629,7 +675,7 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* 
     const double ln_opc = a[NFW_NS2 + 0], inv_mc = a[NFW_NS2 + 1], inv_opc2 = a[NFW_NS2 + 2];
     const bool use_series = (a[0] != 0.0);
     double* __restrict__ dst = uk + (size_t)row * nk;
-    for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
+    for (int k = k_lo + threadIdx.x; k < k_hi; k += nthr) {
         const double x = ks[k] * rs * z1;
         const double xc = opc * x;
         if (use_series && xc <= 4.0) {
@@ -720,6 +766,13 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* 
         // sin(cx)/((1+c)x) = scx * xc / xc^2
         __builtin_nontemporal_store((s1 * (si2 - si1) - scx * (xc * zc) + c1 * dci) * inv_mc, &dst[k]);
     }
+}
+__global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* __restrict__ T,
+                                                  const double* __restrict__ acoef, int ktile, int nm, int nk,
+                                                  const double* __restrict__ cs, const double* __restrict__ rss,
+                                                  const double* __restrict__ zs, const double* __restrict__ ks,
+                                                  double* __restrict__ uk) {
+    nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, blockIdx.x, blockDim.x);
 }
 
 // ---------------------------------------------------------------- A8/X1: row parameters
@@ -1045,13 +1098,11 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
 // length of the Battaglia profiles) - strides, twiddle steps and the j/Ns multipliers become immediates and
 // the pass loop with its dispatch chain unrolls.
 template <int NT, int MAXB, int MAXP, int SPECM>
-__global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_fused_kernel(FusedArgs A) {
+__device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, double* smem) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
     // scratch, the broadcast mass norm and the left-fill counter.
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     cplx* buf = reinterpret_cast<cplx*>(smem);
-    const int row = blockIdx.x;
     const int M = SPECM ? SPECM : A.plan.M, nxs = SPECM ? 2 * SPECM : A.nxs;
     double* red = smem + 2 * (size_t)M;
     int* s_cnt = reinterpret_cast<int*>(red + 17);
@@ -1247,6 +1298,11 @@ __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_f
         }
     }
 }
+template <int NT, int MAXB, int MAXP, int SPECM>
+__global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_fused_kernel(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    profile_fused_row<NT, MAXB, MAXP, SPECM>(A, blockIdx.x, smem);
+}
 
 // ---------------------------------------------------------------- K7: HOD (H1-H3)
 // 10^y and x^p through exp2/log2 (one transcendental each instead of the ~6x longer generic
@@ -1297,57 +1353,101 @@ struct HodDev {
     int corr;
 };
 
-// One block per z.  The 4000-point inverse-SHMR table lives in LDS (32 KB).
-__global__ __launch_bounds__(1024) void hod_kernel(int nm, HodDev P, const double* __restrict__ zs,
-                                                  const double* __restrict__ ms,
-                                                  const double* __restrict__ lthr,
-                                                  const double* __restrict__ nzm,
-                                                  const double* __restrict__ bh,
-                                                  const double* __restrict__ wm,
-                                                  double* __restrict__ Nc, double* __restrict__ Ns,
-                                                  double* __restrict__ NsNsm1,
-                                                  double* __restrict__ NcNs,
-                                                  double* __restrict__ ngal, double* __restrict__ bg) {
+// The same inversion without the table: the bracket search evaluates the table entries it visits on the
+// fly (12 of the 4000 per mass).  Entry j is shmr_log10mh(shmr_grid(j)) in both forms, so the bracket, the
+// knots and the interpolated value are the same numbers - but nothing has to be built first and no LDS is
+// held, which is what lets the HOD of a redshift run as one link of a per-z chain inside a grouped launch
+// beside workgroups of another kind (LDS is allocated per launch, for every workgroup alike).
+__device__ __forceinline__ double shmr_inverse_direct(double lmh, double a, const ShmrSet& S) {
+    const double m0 = shmr_log10mh(shmr_grid(0), a, S);
+    if (lmh < m0) return shmr_grid(0);
+    const double mN = shmr_log10mh(shmr_grid(SHMR_N - 1), a, S);
+    if (lmh >= mN) return shmr_grid(SHMR_N - 1);
+    int lo = 0, hi = SHMR_N - 1;          // mh[lo] <= lmh < mh[hi]
+    double mlo = m0, mhi = mN;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        const double mm = shmr_log10mh(shmr_grid(mid), a, S);
+        if (mm <= lmh) { lo = mid; mlo = mm; } else { hi = mid; mhi = mm; }
+    }
+    if (mlo == lmh) return shmr_grid(lo);
+    const double slope = (shmr_grid(lo + 1) - shmr_grid(lo)) / (mhi - mlo);
+    return slope * (lmh - mlo) + shmr_grid(lo);
+}
+
+struct HodRowArgs {
+    int nm;
+    HodDev P;
+    const double *zs, *ms, *lthr, *nzm, *bh, *wm;
+    double *Nc, *Ns, *NsNsm1, *NcNs, *ngal, *bg;
+};
+constexpr int HOD_MAX_TILES = 1024;      // 64-mass tiles per redshift (nm <= 65536)
+
+// The HOD has two halves.  The occupation numbers <Nc>, <Ns>, <Ns(Ns-1)>, <NcNs> of a (z,m) point depend on
+// INPUTS only (z, m, the stellar-mass threshold, the HOD parameters) - and carry all the cost: the SHMR
+// inversion, an erf, two powers, an exp.  n_gal and b_g are sums over m of those times n(z,m), b(z,m).  A
+// grouped pass therefore evaluates the occupations in its FRONT launch beside the sigma^2 contraction (no
+// register cap there, one thread per point) and leaves only the sums to the per-z chain.
+__device__ __forceinline__ void hod_occ_point(const HodRowArgs& A, int z, int m) {
 #pragma clang fp contract(off)
-    __shared__ double mh[SHMR_N];
-    __shared__ double lds[16];
-    const int z = blockIdx.x;
-    const double zz = zs[z], a = 1.0 / (1.0 + zz);
+    const HodDev& P = A.P;
+    const double zz = A.zs[z], a = 1.0 / (1.0 + zz);
     const ShmrSet S = shmr_for(zz);
-    for (int j = threadIdx.x; j < SHMR_N; j += blockDim.x) mh[j] = shmr_log10mh(shmr_grid(j), a, S);
-    __syncthreads();
-    const double thr = lthr[z];
+    const double thr = A.lthr[z];
     const double mthr_halo = shmr_log10mh(thr, a, S);
     const double Msat = 1.0e12 * P.Bsat * pow10_fast((mthr_halo - 12.0) * P.betasat);
     const double Mcut = 1.0e12 * P.Bcut * pow10_fast((mthr_halo - 12.0) * P.betacut);
     const double denom = sqrt(2.0) * P.sig;
-    double acc_n = 0.0, acc_b = 0.0;
-    for (int m = threadIdx.x; m < nm; m += blockDim.x) {
-        const double lmh = log10(ms[m]);
-        const double lmstar = shmr_inverse(mh, lmh);
-        const double nc = 0.5 * (1.0 - erf((thr - lmstar) / denom));
-        const double mass = pow10_fast(lmh);
-        const double ns = nc * powr_fast(mass / Msat, P.alphasat) * exp(-Mcut / mass);
-        double nn, cn;
-        if (P.corr == 0) {
-            nn = (fabs(nc) <= 1.0e-8) ? 0.0 : (ns * ns) / nc;   // np.isclose(Nc, 0)
-            cn = ns;
-        } else {
-            nn = ns * ns;
-            cn = ns * nc;
+    const double lmh = log10(A.ms[m]);
+    const double lmstar = shmr_inverse_direct(lmh, a, S);
+    const double nc = 0.5 * (1.0 - erf((thr - lmstar) / denom));
+    const double mass = pow10_fast(lmh);
+    const double ns = nc * powr_fast(mass / Msat, P.alphasat) * exp(-Mcut / mass);
+    double nn, cn;
+    if (P.corr == 0) {
+        nn = (fabs(nc) <= 1.0e-8) ? 0.0 : (ns * ns) / nc;   // np.isclose(Nc, 0)
+        cn = ns;
+    } else {
+        nn = ns * ns;
+        cn = ns * nc;
+    }
+    const size_t idx = (size_t)z * A.nm + m;
+    A.Nc[idx] = nc; A.Ns[idx] = ns; A.NsNsm1[idx] = nn; A.NcNs[idx] = cn;
+}
+
+// n_gal(z), b_g(z) of one redshift by one workgroup of nthr threads, from the stored occupations.  The order
+// is fixed by nm alone: wavefront sums over the 64-mass tiles, then the tiles in order - whatever the
+// workgroup size.  part: 2 * ceil(nm/64) doubles of LDS.
+__device__ __forceinline__ void hod_sums_row(const HodRowArgs& A, int z, int nthr, double* part) {
+#pragma clang fp contract(off)
+    const int nm = A.nm, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = nthr >> 6;
+    const int ntile = (nm + 63) / 64;
+    for (int tile = w; tile < ntile; tile += nw) {
+        const int m = tile * 64 + lane;
+        double t = 0.0, tb = 0.0;
+        if (m < nm) {
+            const size_t idx = (size_t)z * nm + m;
+            t = A.wm[m] * (A.nzm[idx] * (A.Nc[idx] + A.Ns[idx]));
+            tb = t * A.bh[idx];
         }
-        const size_t idx = (size_t)z * nm + m;
-        Nc[idx] = nc; Ns[idx] = ns; NsNsm1[idx] = nn; NcNs[idx] = cn;
-        const double t = wm[m] * (nzm[idx] * (nc + ns));
-        acc_n += t;
-        acc_b += t * bh[idx];
+        const double tn = wave_sum(t), tbs = wave_sum(tb);
+        if (lane == 0) { part[2 * tile] = tn; part[2 * tile + 1] = tbs; }
     }
-    const double tn = block_sum(acc_n, lds);
-    const double tb = block_sum(acc_b, lds);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        ngal[z] = tn;
-        bg[z] = tb / tn;
+        double sn = 0.0, sb = 0.0;
+        for (int tile = 0; tile < ntile; ++tile) { sn += part[2 * tile]; sb += part[2 * tile + 1]; }
+        A.ngal[z] = sn;
+        A.bg[z] = sb / sn;
     }
+}
+
+// One block per z: both halves.
+__global__ __launch_bounds__(1024) void hod_kernel(HodRowArgs A) {
+    __shared__ double part[2 * HOD_MAX_TILES];
+    for (int m = threadIdx.x; m < A.nm; m += blockDim.x) hod_occ_point(A, blockIdx.x, m);
+    __syncthreads();
+    hod_sums_row(A, blockIdx.x, blockDim.x, part);
 }
 
 // ---------------------------------------------------------------- K6: fused mass integrals (P1-P4)
@@ -1626,15 +1726,23 @@ struct BatchPrep {
 // grid (nz, nblk) with 64-thread blocks, one (z,m) per thread; the k->0 consistency sums C_t
 // and HOD bias numerators B_t are written as per-block partials sidep[z][blk][t][2] = {B, C}
 // and summed in block order by the main kernel's epilogue (deterministic).
-__global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep Q,
-                                                              const double* __restrict__ nzm,
-                                                              const double* __restrict__ bh,
-                                                              const double* __restrict__ ms,
-                                                              const double* __restrict__ wm,
-                                                              double* __restrict__ coef,
-                                                              double* __restrict__ sidep) {
-    const int z = blockIdx.x, blk = blockIdx.y, nblk = gridDim.y;
-    const int m = blk * 64 + threadIdx.x;
+struct PrepArgs {
+    int nm, nblk;
+    BatchPrep Q;
+    const double *nzm, *bh, *ms, *wm;
+    double *coef, *sidep;
+};
+// one wavefront = the 64 masses of tile blk of redshift z
+__device__ __forceinline__ void batch_prep_tile(const PrepArgs& PA, int z, int blk) {
+    const int nm = PA.nm, nblk = PA.nblk;
+    const BatchPrep& Q = PA.Q;
+    const double* __restrict__ nzm = PA.nzm;
+    const double* __restrict__ bh = PA.bh;
+    const double* __restrict__ ms = PA.ms;
+    const double* __restrict__ wm = PA.wm;
+    double* __restrict__ coef = PA.coef;
+    double* __restrict__ sidep = PA.sidep;
+    const int m = blk * 64 + (threadIdx.x & 63);
     const int nc1 = 1 + Q.nt;
     const int stride = pb_stride(Q.code, Q.ntr, nc1);
     double accC[PB_MAXTR], accB[PB_MAXTR];
@@ -1684,12 +1792,75 @@ __global__ __launch_bounds__(64) void power_batch_prep_kernel(int nm, BatchPrep 
     for (int t = 0; t < Q.ntr; ++t) {
         const double C = wave_sum(accC[t]);
         const double B = wave_sum(accB[t]);
-        if (threadIdx.x == 0) {
+        if ((threadIdx.x & 63) == 0) {
             double* sp = sidep + ((size_t)(z * nblk + blk) * Q.ntr + t) * 2;
             sp[0] = B;
             sp[1] = C;
         }
     }
+}
+// The same rows for a batch with a structure code (every batch of PB_SPEC_LIST), written without the
+// generic forms' dynamically indexed coefficient arrays: a handful of registers, so that it can run as a
+// link of the per-z chain inside the profile group under that kernel's 64-register budget without spilling
+// (a spill anywhere gives the whole launch a scratch allocation, which cost the fused profile rows 7 %).
+// Same numbers as batch_prep_tile: the generic forms add these terms to exact zeros.
+__device__ __forceinline__ void batch_prep_tile_compact(const PrepArgs& PA, int z, int blk) {
+    const BatchPrep& Q = PA.Q;
+    const int nm = PA.nm, lane = threadIdx.x & 63, m = blk * 64 + lane;
+    int ncoef = 2;
+#pragma unroll
+    for (int t = 0; t < PB_MAXTR; ++t)
+        if (t < Q.ntr) ncoef += Q.tr[t].kind == HMG_TRACER_HOD ? 4 : 1;
+    const int stride = (ncoef + 7) & ~7;
+    double accC[PB_MAXTR], accB[PB_MAXTR];
+#pragma unroll
+    for (int t = 0; t < PB_MAXTR; ++t) accC[t] = accB[t] = 0.0;
+    if (m < nm) {
+        const size_t idx = (size_t)z * nm + m;
+        const double mass = PA.ms[m];
+        const double wn = PA.wm[m] * PA.nzm[idx];
+        const double wnb = wn * PA.bh[idx];
+        double* __restrict__ c = PA.coef + idx * (size_t)stride;
+        c[0] = wn;
+        c[1] = wnb;
+        int pos = 2;
+#pragma unroll
+        for (int t = 0; t < PB_MAXTR; ++t) {
+            if (t >= Q.ntr) continue;
+            const TracerDev& T = Q.tr[t];
+            double low = 0.0;
+            if (T.kind == HMG_TRACER_HOD) {
+                const double ng = T.ngal[z], ng2 = ng * ng, nc = T.Nc[idx], ns = T.Ns[idx];
+                c[pos] = nc / ng;
+                c[pos + 1] = ns / ng;
+                c[pos + 2] = 2.0 * T.NcNs[idx] / ng2;
+                c[pos + 3] = T.NsNsm1[idx] / ng2;
+                pos += 4;
+                accB[t] = wnb * (nc + ns);
+                low = (nc + ns) / ng;
+            } else {
+                low = T.kind == HMG_TRACER_MATTER ? mass / Q.rho_m0 : 0.0;
+                c[pos++] = T.kind == HMG_TRACER_MATTER ? low : 1.0;
+            }
+            accC[t] = wnb * low;
+        }
+        for (; pos < stride; ++pos) c[pos] = 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < PB_MAXTR; ++t) {
+        if (t >= Q.ntr) continue;
+        const double C = wave_sum(accC[t]);
+        const double B = wave_sum(accB[t]);
+        if (lane == 0) {
+            double* sp = PA.sidep + ((size_t)(z * PA.nblk + blk) * Q.ntr + t) * 2;
+            sp[0] = B;
+            sp[1] = C;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void power_batch_prep_kernel(PrepArgs PA) {
+    if (PA.Q.code) batch_prep_tile_compact(PA, blockIdx.x, blockIdx.y);
+    else batch_prep_tile(PA, blockIdx.x, blockIdx.y);
 }
 
 struct BatchArgs {
@@ -1927,6 +2098,154 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs
             }
         }
     }
+}
+
+// ---------------------------------------------------------------- grouped launches
+// Stages of a pass that do not depend on each other share ONE launch as disjoint block ranges of one grid:
+// a kernel boundary costs ~2 us and on a thin z-slab (the rank of an 8-GPU job holds 4 redshifts) every
+// per-(z,m) launch is pure latency - sigma^2 17 us, HOD 9, coefficient rows 6, row parameters 5 against
+// 90 us for the three chip-filling kernels.  Streams do not help on this runtime (a cross-stream
+// dependency costs more than it hides); block ranges do: the short, latency-bound
+// workgroups come first in the grid, are dispatched first and finish while the long ones still fill the chip.
+//   front   (64 threads):  halo stage points | sigma^2 contraction blocks           - both need inputs only
+//   rows    (256 threads): per-z chain | Battaglia row parameters | analytic NFW rows - need the front
+//   profile (512 threads): per-z chain | fused radial-profile rows                   - needs the rows group
+// The per-z CHAIN is what the mass integrals wait for besides the tensors: second stage of sigma^2 + n, b
+// -> HOD -> coefficient rows of the batched mass integrals, one workgroup per redshift, each link optional.
+// Every role runs the device function of its stand-alone kernel, so grouped and separate launches give
+// the same bits (tests/test_gpu_groups.py).
+struct SigmaFrontArgs {
+    int nz, nzp, nm, nq, gx, nseg;
+    const double *PT, *kq, *wq, *R;
+    double tswitch;
+    double* partial;
+};
+template <int ZB>
+__global__ __launch_bounds__(64, HMG_SIG_OCC) void front_group_kernel(SigmaFrontArgs G, HaloStageArgs H, int nhalo,
+                                                                     HodRowArgs O, int nocc) {
+    int b = blockIdx.x;
+    if (b < nocc) {               // HOD occupations: the longest dependent chain of the launch, so first in the grid
+        const int idx = b * 64 + threadIdx.x;
+        if (idx < G.nz * O.nm) hod_occ_point(O, idx / O.nm, idx - (idx / O.nm) * O.nm);
+        return;
+    }
+    b -= nocc;
+    if (b < nhalo) {
+        const int idx = b * 64 + threadIdx.x;
+        if (idx < H.nz * H.nm) halo_stage_point(H, idx);
+        return;
+    }
+    b -= nhalo;
+    const int r = b / G.gx, bx = b - r * G.gx;
+    const int bz = r / G.nseg, seg = r - bz * G.nseg;
+    sigma2_mfma_block<ZB>(bx, seg, bz, G.nz, G.nzp, G.nm, G.nq, G.PT, G.kq, G.wq, G.R, G.tswitch, G.partial);
+}
+
+struct ChainArgs {
+    int has_hod, has_prep;
+    HodRowArgs H;
+    PrepArgs PA;
+};
+// doubles of LDS a chain workgroup needs
+static inline size_t chain_lds_doubles(int nm) { return 2 * (size_t)((nm + 63) / 64); }
+// The chain is kept LIGHT on purpose - the n_gal, b_g sums of an HOD and the compact coefficient rows: loads, a
+// few divisions, wavefront sums - so that it fits the register budget of the launch it rides in without a
+// spill.  Everything heavy of the HOD (its occupation numbers: SHMR inversion, erf, powers) is in the front
+// launch or, when there is no front to ride with, in hmg_hod's own kernel.
+#define HMG_KERNARG __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const T HMG_KERNARG* uniform_kernarg(const T HMG_KERNARG* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const T HMG_KERNARG*)(((unsigned long long)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T kernarg_load(const T HMG_KERNARG* p) {      // a by-value copy out of the segment,
+    static_assert(sizeof(T) % 8 == 0, "pad the argument block to 8 bytes");   // word by word through the constant
+    union { T v; unsigned long long w[sizeof(T) / 8]; } u;                   // address space (-> scalar loads)
+    const unsigned long long HMG_KERNARG* q = (const unsigned long long HMG_KERNARG*)p;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 8; ++i) u.w[i] = q[i];
+    return u.v;
+}
+template <int NT>
+__device__ __forceinline__ void chain_row(const ChainArgs& C, int z, double* lds) {
+    if (C.has_hod) {
+        hod_sums_row(C.H, z, NT, lds);
+        __syncthreads();
+    }
+    if (C.has_prep)
+        for (int blk = threadIdx.x >> 6; blk < C.PA.nblk; blk += NT / 64) batch_prep_tile_compact(C.PA, z, blk);
+}
+
+struct RowsArgs {
+    int n;            // nz*nm, 0: no such role in this launch
+    int kind, nm;
+    const double *m200, *r200, *rvir, *zs, *rhoc, *hz;
+    RowFit F;
+    double gamma, alpha_const, pref, post_pref;
+    RowOut O;
+};
+__device__ __attribute__((noinline)) void rows_block(const RowsArgs HMG_KERNARG* rp_in, int b_in) {
+    const RowsArgs Rw = kernarg_load(uniform_kernarg(rp_in));
+    const int idx = __builtin_amdgcn_readfirstlane(b_in) * 256 + threadIdx.x;
+    if (idx < Rw.n) {
+        const int z = idx / Rw.nm;
+        rowparams_body(Rw.kind, idx, Rw.m200[idx], Rw.r200[idx], Rw.rvir[idx], 1.0 + Rw.zs[z], Rw.rhoc[z],
+                       Rw.hz ? Rw.hz[z] : 1.0, Rw.F, Rw.gamma, Rw.alpha_const, Rw.pref, Rw.post_pref, Rw.O);
+    }
+}
+__device__ __attribute__((noinline)) void massfn_block(const SigmaMassFnArgs HMG_KERNARG* sp_in, int b_in, int ntile) {
+    __shared__ double red[4 * 64];
+    __shared__ double sig[64];
+    const SigmaMassFnArgs S = kernarg_load(uniform_kernarg(sp_in));
+    const int b = __builtin_amdgcn_readfirstlane(b_in), nt = __builtin_amdgcn_readfirstlane(ntile);
+    sigma2_massfn_tile(S, b / nt, b - (b / nt) * nt, red, sig);
+}
+struct RowsGroupArgs {       // the FIRST kernel parameter, so that the cold roles can address their part of it in place
+    ChainArgs C;
+    RowsArgs Rw;
+    SigmaMassFnArgs S;
+    int nchain, nrowblk, nmfblk, mf_ntile;
+};
+// (the NFW role's pointers are kernel parameters of their own: see nfw_rows)
+__global__ __launch_bounds__(256, HMG_NFW_OCC) void rows_group_kernel(RowsGroupArgs G, const SiciTable* __restrict__ T,
+                                                                      const double* __restrict__ acoef, int ktile, int nm,
+                                                                      int nk, const double* __restrict__ cs,
+                                                                      const double* __restrict__ rss,
+                                                                      const double* __restrict__ zs,
+                                                                      const double* __restrict__ ks,
+                                                                      double* __restrict__ uk) {
+    extern __shared__ double lds[];
+    const RowsGroupArgs HMG_KERNARG* kp = (const RowsGroupArgs HMG_KERNARG*)__builtin_amdgcn_kernarg_segment_ptr();
+    int b = blockIdx.x;
+    if (b < G.nchain) {
+        chain_row<256>(G.C, b, lds);
+        return;
+    }
+    b -= G.nchain;
+    if (b < G.nmfblk) {
+        massfn_block(&kp->S, b, G.mf_ntile);
+        return;
+    }
+    b -= G.nmfblk;
+    if (b < G.nrowblk) {
+        rows_block(&kp->Rw, b);
+        return;
+    }
+    nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, b - G.nrowblk, 256);
+}
+
+template <int MAXB, int MAXP, int SPECM>
+__global__ __launch_bounds__(512, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_group_kernel(ChainArgs C, FusedArgs A,
+                                                                                              int nchain) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    if (b < nchain) {
+        chain_row<512>(C, b, smem);
+        return;
+    }
+    profile_fused_row<512, MAXB, MAXP, SPECM>(A, b - nchain, smem);
 }
 
 // ---------------------------------------------------------------- N1: Limber integral
@@ -2652,6 +2971,7 @@ static int sigma2_partials(hmg_ctx* c, int nz, int nm, int nq, const double* PT,
         hipLaunchKernelGGL(sigma2_mfma_kernel<1>, grid, dim3(64), 0, c->stream, nz, nzp, nm, nq,
                            PT, kq, wq, R, tswitch, partial);
     HIP_TRY(hipGetLastError());
+    c->sig_nz = nz; c->sig_nm = nm; c->sig_nq = nq;
     *partial_out = partial;
     *nseg_out = nseg;
     return 0;
@@ -2914,12 +3234,34 @@ static int launch_fused(hmg_ctx* c, const FusedArgs& A, int rows) {
     return 0;
 }
 
-int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, const double* xs, const double* kts,
-                    const double* amp, const double* xcs, const double* alpha, const double* expo,
-                    double amp_c, double xc_c, double alpha_c, double expo_c, double gamma,
-                    const double* cmax, const double* rss, const double* zs, const double* ks,
-                    int do_mass_norm, const double* post, double* out, int* nconst, double* cconst,
-                    const double* logxs) {
+// profile_group_kernel = the fused row kernel with `nchain` per-z chain workgroups in front of the rows
+template <int MAXB, int MAXP, int SPECM = 0>
+static int launch_fused_group(hmg_ctx* c, const FusedArgs& A, int rows, const ChainArgs& C, int nchain, size_t chain_lds) {
+    size_t lds = (size_t)A.plan.M * 16 + 32 * sizeof(double);
+    if (chain_lds > lds) lds = chain_lds;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)profile_group_kernel<MAXB, MAXP, SPECM>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((profile_group_kernel<MAXB, MAXP, SPECM>), dim3(rows + nchain), dim3(FUSED_NT), lds, c->stream, C,
+                       A, nchain);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One hmg_profile_fft; with a chain (nchain > 0) and a length the in-LDS transform takes, chain and rows share
+// the launch, otherwise *chain_done stays 0 and the caller issues the chain on its own.
+static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part& p, const ChainArgs* C,
+                            int nchain, size_t chain_lds, int* chain_done) {
+    const int nxs = p.nxs;
+    const double step = p.fft_step;
+    const double *xs = p.d_xs, *kts = p.d_kts, *amp = p.d_amp, *xcs = p.d_xc, *alpha = p.d_alpha, *expo = p.d_expo;
+    const double amp_c = p.amp_const, xc_c = p.xc_const, alpha_c = p.alpha_const, expo_c = p.expo_const, gamma = p.gamma;
+    const double *cmax = p.d_cmax, *rss = p.d_rss, *zs = p.d_zs, *ks = p.d_ks, *post = p.d_post, *logxs = p.d_logxs;
+    const int do_mass_norm = p.do_mass_norm;
+    double* out = p.d_out;
+    int* nconst = p.d_nconst;
+    double* cconst = p.d_cconst;
+    if (chain_done) *chain_done = 0;
     REQUIRE(c && xs && kts && cmax && rss && zs && ks && out, "NULL argument");
     REQUIRE((nconst == nullptr) == (cconst == nullptr), "pass both hint arrays or neither");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
@@ -2955,7 +3297,16 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
             const bool spec2500 = FUSED_NT == 512 && pl.M == 2500 && pl.npass == 5 && pl.radix[0] == 4 && pl.radix[1] == 5 &&
                                   pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
                                   !getenv("HMG_FUSED_GENERIC");      // (testing: force the run-time plan)
-            if (spec2500) rc = launch_fused<2, 3, 2500>(c, A, rows);                 // nxs = 5000, compile-time plan
+            const bool grouped = C && nchain > 0 && FUSED_NT == 512;
+            if (grouped) {
+                if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds);
+                else if (mb <= 1 && mp <= 2) rc = launch_fused_group<1, 2>(c, A, rows, *C, nchain, chain_lds);
+                else if (mb <= 2 && mp <= 3) rc = launch_fused_group<2, 3>(c, A, rows, *C, nchain, chain_lds);
+                else if (mb <= 2 && mp <= 4) rc = launch_fused_group<2, 4>(c, A, rows, *C, nchain, chain_lds);
+                else rc = launch_fused_group<4, 8>(c, A, rows, *C, nchain, chain_lds);
+                if (!rc && chain_done) *chain_done = 1;
+            }
+            else if (spec2500) rc = launch_fused<2, 3, 2500>(c, A, rows);                 // nxs = 5000, compile-time plan
             else if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
             else if (mb <= 2 && mp <= 3) rc = launch_fused<2, 3>(c, A, rows);
             else if (mb <= 2 && mp <= 4) rc = launch_fused<2, 4>(c, A, rows);
@@ -3003,6 +3354,17 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
     return bracket_close(c, stop);
 }
 
+int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, const double* xs, const double* kts,
+                    const double* amp, const double* xcs, const double* alpha, const double* expo,
+                    double amp_c, double xc_c, double alpha_c, double expo_c, double gamma,
+                    const double* cmax, const double* rss, const double* zs, const double* ks,
+                    int do_mass_norm, const double* post, double* out, int* nconst, double* cconst,
+                    const double* logxs) {
+    const hmg_profile_fft_part p{nxs, step, xs, kts, amp, xcs, alpha, expo, amp_c, xc_c, alpha_c, expo_c, gamma,
+                                 cmax, rss, zs, ks, do_mass_norm, post, out, nconst, cconst, logxs};
+    return profile_fft_impl(c, nz, nm, nk, p, nullptr, 0, 0, nullptr);
+}
+
 int hmg_profile_fft_logx(hmg_ctx* c, int nxs, const double* xs, double* logxs) {
     REQUIRE(c && xs && logxs && nxs > 0, "bad argument");
     hipLaunchKernelGGL(logx_kernel, grid1d((size_t)nxs, 256), dim3(256), 0, c->stream, nxs, xs, logxs);
@@ -3021,8 +3383,10 @@ int hmg_hod(hmg_ctx* c, int nz, int nm, const hmg_hod_params* p, const double* z
     int hod_threads = 1024;
     if (const char* e = getenv("HMG_HOD_THREADS")) hod_threads = atoi(e);
     REQUIRE(hod_threads >= 64 && hod_threads <= 1024 && hod_threads % 64 == 0, "HMG_HOD_THREADS must be a multiple of 64 up to 1024");
-    hipLaunchKernelGGL(hod_kernel, dim3(nz), dim3(hod_threads), 0, c->stream, nm, P, zs, ms, lthr, nzm, bh, wm,
-                       Nc, Ns, NsNsm1, NcNs, ngal, bg);
+    REQUIRE((nm + 63) / 64 <= HOD_MAX_TILES, "nm too large for the HOD reduction (65536)");
+    if (!getenv("HMG_HOD_THREADS")) hod_threads = std::min(1024, std::max(64, (nm + 63) / 64 * 64));
+    const HodRowArgs A{nm, P, zs, ms, lthr, nzm, bh, wm, Nc, Ns, NsNsm1, NcNs, ngal, bg};
+    hipLaunchKernelGGL(hod_kernel, dim3(nz), dim3(hod_threads), 0, c->stream, A);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3142,11 +3506,25 @@ static int launch_power_batch(hmg_ctx* c, const BatchArgs& A, int nz) {
     return bracket_close(c, stop);
 }
 
-int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_tracer* tr_in, int npairs,
-                    const int* pair_a, const int* pair_b, const double* nzm, const double* bh,
-                    const double* ms, const double* wm, const double* ks, const double* Pzk,
-                    double rho_m0, double kstar, double* const* P1h, double* const* P2h) {
-    REQUIRE(c && tr_in && pair_a && pair_b && nzm && bh && ms && wm && ks, "NULL argument");
+// Everything hmg_power_batch decides on the host: canonical tracer order, structure code, the argument blocks
+// of the two launches and the launch shape.  Deterministic in its inputs, so that a preparation issued from a
+// grouped launch and the main launch issued later agree on every pointer.
+struct PbPlan {
+    BatchPrep Q;
+    PrepArgs PA;
+    BatchArgs A;
+    int ntr = 0, nt = 0, thin = 0;
+    unsigned code = 0;
+    bool vec2 = false;
+};
+static int pb_plan(hmg_ctx* c, int nz, int nm, int nk, const hmg_power_batch_desc* d, PbPlan* P) {
+    REQUIRE(c && d && P, "NULL argument");
+    const int ntr = d->ntr, npairs = d->npairs;
+    const hmg_tracer* tr_in = d->h_tr;
+    const int *pair_a = d->h_pair_a, *pair_b = d->h_pair_b;
+    double* const* P1h = d->h_P1h;
+    double* const* P2h = d->h_P2h;
+    REQUIRE(tr_in && pair_a && pair_b && d->d_nzm && d->d_bh && d->d_ms && d->d_wm && d->d_ks, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
     REQUIRE(nz <= 65535, "nz too large");
     REQUIRE(ntr >= 1 && ntr <= PB_MAXTR, "1..4 tracers per batch");
@@ -3170,14 +3548,14 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
                 if (group(t) == pass) { tr[n] = tr_in[t]; where[t] = n++; }
     }
     std::vector<const double*> tens;
-    BatchPrep Q;
+    BatchPrep& Q = P->Q;
     for (int t = 0; t < ntr; ++t) {
         REQUIRE(!tr[t].d_bias_override, "bias overrides are not supported in the batched kernel");
         if (fill_tracer(&tr[t], tens, &Q.tr[t])) return 1;
     }
     Q.ntr = ntr;
     Q.nt = (int)tens.size();
-    Q.rho_m0 = rho_m0;
+    Q.rho_m0 = d->rho_m0;
     REQUIRE(Q.nt >= 1 && Q.nt <= PW_MAXT, "more than 4 distinct profile tensors in one batch");
     // structure code of the batch (0 if a tracer has no compact form: an HOD with a central profile)
     unsigned code = 0;
@@ -3187,7 +3565,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
         code |= (hod ? PB_HOD(Q.tr[t].t_prof) : PB_LIN(Q.tr[t].t_prof)) << (4 * t);
     }
     if (getenv("HMG_PB_GENERIC")) code = 0;            // (testing: the generic forms for every batch)
-    BatchArgs A;
+    BatchArgs& A = P->A;
     for (int p = 0; p < PB_MAXPAIR; ++p) A.P1h[p] = A.P2h[p] = nullptr;
     bool any2 = false;
     for (int i = 0; i < npairs; ++i) {
@@ -3200,7 +3578,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
         if (P1h && P1h[i]) A.P1h[p] = P1h[i];
         if (P2h && P2h[i]) { A.P2h[p] = P2h[i]; any2 = true; }
     }
-    REQUIRE(!any2 || Pzk, "P2h needs Pzk");
+    REQUIRE(!any2 || d->d_Pzk, "P2h needs Pzk");
     // the structures the kernel is compiled for; anything else runs the generic forms
     static const struct { int nt, ntr; unsigned code; } spec_list[] = {
 #define PB_SPEC(NT_, NTR_, ...) {NT_, NTR_, pb_code(__VA_ARGS__)},
@@ -3218,8 +3596,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     if (ensure_scratch(c, 3, (size_t)nz * nm * stride * 8 + (size_t)nz * nblk * ntr * 2 * 8 + 64)) return 1;
     double* coef = (double*)c->scratch[3];
     double* sidep = coef + (size_t)nz * nm * stride;
-    hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, nblk), dim3(64), 0, c->stream, nm, Q, nzm, bh, ms, wm, coef, sidep);
-    HIP_TRY(hipGetLastError());
+    P->PA = PrepArgs{nm, nblk, Q, d->d_nzm, d->d_bh, d->d_ms, d->d_wm, coef, sidep};
     for (int i = 0; i < PW_MAXT; ++i) {
         A.tens[i] = i < Q.nt ? tens[i] : nullptr;
         A.nconst[i] = nullptr;
@@ -3237,7 +3614,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
         A.bias_const[t] = (t < ntr && tr[t].kind == HMG_TRACER_MATTER) ? 1.0 : 0.0;
     }
     A.nblk = nblk;
-    A.coef = coef; A.sidep = sidep; A.ks = ks; A.Pzk = Pzk; A.kstar = kstar; A.nm = nm; A.nk = nk;
+    A.coef = coef; A.sidep = sidep; A.ks = d->d_ks; A.Pzk = d->d_Pzk; A.kstar = d->kstar; A.nm = nm; A.nk = nk;
     bool vec2 = (nk % 2 == 0);
     for (int i = 0; i < Q.nt; ++i) vec2 = vec2 && (((uintptr_t)tens[i]) % 16 == 0);
     // thin z-slabs: narrower k tiles so that every CU still gets a workgroup, and sixteen wavefronts per
@@ -3252,6 +3629,15 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
     if (const char* e = getenv("HMG_PB_THIN")) thin = atoi(e);      // tuning/testing: force a shape (2: V=1, 8 wavefronts)
     if (thin == 3 && !vec2) thin = 1;
     if (thin == 1 || thin == 2) vec2 = false;
+    P->ntr = ntr; P->nt = Q.nt; P->thin = thin; P->code = code; P->vec2 = vec2;
+    return 0;
+}
+
+static int pb_launch_main(hmg_ctx* c, const PbPlan& P, int nz) {
+    const BatchArgs& A = P.A;
+    const int thin = P.thin, ntr = P.ntr;
+    const bool vec2 = P.vec2;
+    const unsigned code = P.code;
 #define PB_SHAPES(NT_, NTR_, CODE_)                                                        \
     if (thin == 3) return launch_power_batch<NT_, NTR_, 2, true, CODE_>(c, A, nz);         \
     return thin == 1 ? launch_power_batch<NT_, NTR_, 1, true, CODE_>(c, A, nz)             \
@@ -3259,7 +3645,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
                              : launch_power_batch<NT_, NTR_, 1, false, CODE_>(c, A, nz));
     if (code) {
 #define PB_SPEC(NT_, NTR_, ...)                                                            \
-        if (Q.nt == NT_ && ntr == NTR_ && code == pb_code(__VA_ARGS__)) { PB_SHAPES(NT_, NTR_, pb_code(__VA_ARGS__)) }
+        if (P.nt == NT_ && ntr == NTR_ && code == pb_code(__VA_ARGS__)) { PB_SHAPES(NT_, NTR_, pb_code(__VA_ARGS__)) }
         PB_SPEC_LIST
 #undef PB_SPEC
     }
@@ -3272,7 +3658,7 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
         case 4: PB_V(NT_, 4)                \
     }                                       \
     break;
-    switch (Q.nt) {
+    switch (P.nt) {
         case 1: PB_NTR(1)
         case 2: PB_NTR(2)
         case 3: PB_NTR(3)
@@ -3282,6 +3668,184 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
 #undef PB_V
 #undef PB_SHAPES
     return fail("hmg_power_batch", "unreachable", __FILE__, __LINE__);
+}
+
+int hmg_power_batch_run(hmg_ctx* c, int nz, int nm, int nk, const hmg_power_batch_desc* d, int flags) {
+    PbPlan P;
+    if (pb_plan(c, nz, nm, nk, d, &P)) return 1;
+    if (!(flags & HMG_PB_PREPARED)) {
+        hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, P.PA.nblk), dim3(64), 0, c->stream, P.PA);
+        HIP_TRY(hipGetLastError());
+    }
+    return pb_launch_main(c, P, nz);
+}
+
+int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_tracer* tr_in, int npairs,
+                    const int* pair_a, const int* pair_b, const double* nzm, const double* bh,
+                    const double* ms, const double* wm, const double* ks, const double* Pzk,
+                    double rho_m0, double kstar, double* const* P1h, double* const* P2h) {
+    const hmg_power_batch_desc d{ntr, tr_in, npairs, pair_a, pair_b, nzm, bh, ms, wm, ks, Pzk, rho_m0, kstar, P1h, P2h};
+    return hmg_power_batch_run(c, nz, nm, nk, &d, 0);
+}
+
+// ---- grouped launches ---------------------------------------------------------------------------
+static int hod_args(int nm, const hmg_hod_part* hod, HodRowArgs* A) {
+    const hmg_hod_params* p = hod->h_par;
+    REQUIRE(p && hod->d_zs && hod->d_ms && hod->d_log10mstar_thresh && hod->d_Nc && hod->d_Ns && hod->d_NsNsm1 &&
+                hod->d_NcNs, "NULL argument in the HOD part");
+    REQUIRE(hod->stage == HMG_HOD_OCCUPATIONS || (hod->d_nzm && hod->d_bh && hod->d_wm && hod->d_ngal && hod->d_bg),
+            "NULL argument in the HOD part");
+    REQUIRE(p->corr == 0 || p->corr == 1, "corr must be 0 (max) or 1 (min)");
+    REQUIRE((nm + 63) / 64 <= HOD_MAX_TILES, "nm too large for the HOD reduction (65536)");
+    const HodDev P{p->sig_log_mstellar, p->alphasat, p->Bsat, p->betasat, p->Bcut, p->betacut, p->corr};
+    *A = HodRowArgs{nm, P, hod->d_zs, hod->d_ms, hod->d_log10mstar_thresh, hod->d_nzm, hod->d_bh, hod->d_wm,
+                    hod->d_Nc, hod->d_Ns, hod->d_NsNsm1, hod->d_NcNs, hod->d_ngal, hod->d_bg};
+    return 0;
+}
+
+int hmg_sigma2_halo_front(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq, const double* wq,
+                          const double* R, double tswitch, const double* ms, const hmg_halo_stage_args* h,
+                          const hmg_hod_part* hod) {
+    REQUIRE(c && PT && kq && wq && R, "NULL argument");
+    REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
+    HaloStageArgs H;
+    if (halo_stage_check(c, nz, nm, ms, h, &H)) return 1;
+    HodRowArgs O{};
+    int nocc = 0;
+    if (hod) {
+        REQUIRE(hod->stage == HMG_HOD_OCCUPATIONS, "only the occupations of an HOD need inputs only");
+        if (hod_args(nm, hod, &O)) return 1;
+        nocc = (nz * nm + 63) / 64;
+    }
+    const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
+    const int ztile = sigma2_ztile(nz), nzp = sigma2_nzp(nz);
+    if (ensure_scratch(c, 4, (size_t)nseg * nz * nm * 8)) return 1;
+    const int gx = (nm + 15) / 16;
+    const size_t nsig = (size_t)gx * nseg * (nzp / ztile);
+    const int nhalo = (nz * nm + 63) / 64;
+    REQUIRE(nsig + nhalo + nocc <= 2147483647u, "grid too large");
+    const SigmaFrontArgs G{nz, nzp, nm, nq, gx, nseg, PT, kq, wq, R, tswitch, (double*)c->scratch[4]};
+    const dim3 grid((unsigned)(nsig + nhalo + nocc));
+    if (ztile == 32)
+        hipLaunchKernelGGL(front_group_kernel<2>, grid, dim3(64), 0, c->stream, G, H, nhalo, O, nocc);
+    else
+        hipLaunchKernelGGL(front_group_kernel<1>, grid, dim3(64), 0, c->stream, G, H, nhalo, O, nocc);
+    HIP_TRY(hipGetLastError());
+    c->sig_nz = nz; c->sig_nm = nm; c->sig_nq = nq;
+    return 0;
+}
+
+// the optional links of a per-z chain from their parts; *n = 1 if there is any
+static int chain_setup(int nm, const hmg_hod_part* hod, const PbPlan* prep, ChainArgs* C, int* n) {
+    C->has_hod = C->has_prep = 0;
+    if (hod) {
+        REQUIRE(hod->stage == HMG_HOD_SUMS, "a chain takes the n_gal, b_g sums of an HOD (its occupations ride with the front)");
+        if (hod_args(nm, hod, &C->H)) return 1;
+        C->has_hod = 1;
+    }
+    if (prep && prep->code) {           // (generic coefficient rows: their own launch, see hmg_group_profile)
+        C->PA = prep->PA;
+        C->has_prep = 1;
+    }
+    *n = (C->has_hod || C->has_prep) ? 1 : 0;
+    return 0;
+}
+static int massfn_setup(hmg_ctx* c, int nz, int nm, int nq, const hmg_massfn_part* mf, SigmaMassFnArgs* S) {
+    const hmg_massfn_params* p = mf->h_par;
+    REQUIRE(p && mf->d_ms && mf->d_lnms && mf->d_sigma2 && mf->d_nzm && mf->d_bh, "NULL argument in the massfn part");
+    REQUIRE(p->mode == HMG_MF_SHETH_TORMEN || p->mode == HMG_MF_TINKER10, "unknown mass function");
+    REQUIRE(p->mode != HMG_MF_TINKER10 || mf->d_tinker_z, "Tinker mode needs d_tinker_z");
+    REQUIRE(c->sig_nz == nz && c->sig_nm == nm && c->sig_nq == nq && c->scratch[4],
+            "no sigma^2 partial sums of this shape in the context: call hmg_sigma2_halo_front first");
+    const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
+    const MassFnDev P{p->mode, p->deltac, p->st_A, p->st_a, p->st_p, p->rho_m0, p->lnm_uniform, p->lnm_step};
+    *S = SigmaMassFnArgs{nz, nm, nseg, P, (const double*)c->scratch[4], mf->d_ms, mf->d_lnms, mf->d_tinker_z,
+                         mf->d_sigma2, mf->d_nzm, mf->d_bh};
+    return 0;
+}
+
+static int launch_rows_group(hmg_ctx* c, int nz, int nm, const ChainArgs& C, int nchain, const SigmaMassFnArgs* S,
+                             const RowsArgs& Rw, const NfwArgs* N, size_t nfw_blocks) {
+    const int nrowblk = Rw.n ? (Rw.n + 255) / 256 : 0;
+    const int mf_ntile = (nm + MF_TILE - 1) / MF_TILE;
+    const int nmfblk = S ? nz * mf_ntile : 0;
+    const size_t blocks = (size_t)nchain + nmfblk + nrowblk + nfw_blocks;
+    REQUIRE(blocks > 0 && blocks <= 2147483647u, "bad grid");
+    const size_t lds = nchain ? chain_lds_doubles(nm) * 8 : 0;
+    RowsGroupArgs G{};
+    G.C = C; G.Rw = Rw; G.nchain = nchain; G.nrowblk = nrowblk; G.nmfblk = nmfblk; G.mf_ntile = mf_ntile;
+    if (S) G.S = *S;
+    const NfwArgs n = N ? *N : NfwArgs{};
+    hipLaunchKernelGGL(rows_group_kernel, dim3((unsigned)blocks), dim3(256), lds, c->stream, G, n.T, n.acoef, n.ktile,
+                       n.nm, n.nk, n.cs, n.rss, n.zs, n.ks, n.uk);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_group_rows(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_massfn_part* mf, const hmg_hod_part* hod,
+                   const hmg_rows_part* rows, const hmg_nfw_part* nfw) {
+    REQUIRE(c, "NULL ctx");
+    REQUIRE(nz > 0 && nm > 0, "empty grid");
+    REQUIRE(mf || hod || rows || nfw, "empty group");
+    REQUIRE(!(mf && hod), "an HOD needs the n, b of the massfn part: it cannot share its launch");
+    REQUIRE((nm + 63) / 64 <= HOD_MAX_TILES, "nm too large");
+    ChainArgs C;
+    int one = 0;
+    if (chain_setup(nm, hod, nullptr, &C, &one)) return 1;
+    REQUIRE(one || mf || rows || nfw, "empty group");
+    SigmaMassFnArgs S;
+    if (mf && massfn_setup(c, nz, nm, nq, mf, &S)) return 1;
+    RowsArgs Rw{};
+    if (rows) {
+        REQUIRE(rows->d_m200c && rows->d_r200c && rows->d_rvir && rows->d_zs && rows->d_rhocz && rows->d_amp && rows->d_xc &&
+                    rows->d_alpha && rows->d_expo && rows->d_cmax && rows->d_rscale, "NULL argument in the rows part");
+        REQUIRE(rows->kind == HMG_PROF_BATTAGLIA_GAS || rows->kind == HMG_PROF_BATTAGLIA_PRES, "unknown profile kind");
+        REQUIRE(rows->kind != HMG_PROF_BATTAGLIA_PRES || (rows->d_hz && rows->d_post), "pressure needs d_hz and d_post");
+        Rw.n = nz * nm; Rw.kind = rows->kind; Rw.nm = nm;
+        Rw.m200 = rows->d_m200c; Rw.r200 = rows->d_r200c; Rw.rvir = rows->d_rvir; Rw.zs = rows->d_zs;
+        Rw.rhoc = rows->d_rhocz; Rw.hz = rows->d_hz;
+        for (int i = 0; i < 9; ++i) Rw.F.f[i] = rows->fit[i];
+        Rw.gamma = rows->gamma; Rw.alpha_const = rows->alpha_const; Rw.pref = rows->amp_prefactor;
+        Rw.post_pref = rows->post_prefactor;
+        Rw.O = RowOut{rows->d_amp, rows->d_xc, rows->d_alpha, rows->d_expo, rows->d_cmax, rows->d_rscale, rows->d_post};
+    }
+    NfwArgs N{};
+    size_t nfw_blocks = 0;
+    int stop = -1;
+    if (nfw) {
+        REQUIRE(nk > 0, "empty grid");
+        REQUIRE(nfw->d_cs && nfw->d_rs && nfw->d_zs && nfw->d_ks && nfw->d_nfw_series && nfw->d_uk, "NULL argument in the NFW part");
+        const int ktile = 4096;
+        nfw_blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
+        N = NfwArgs{c->d_sici, nfw->d_nfw_series, ktile, nm, nk, nfw->d_cs, nfw->d_rs, nfw->d_zs, nfw->d_ks, nfw->d_uk};
+        if (bracket_open(c, HMG_KERNEL_NFW, &stop)) return 1;
+    }
+    if (launch_rows_group(c, nz, nm, C, one ? nz : 0, mf ? &S : nullptr, Rw, nfw ? &N : nullptr, nfw_blocks)) return 1;
+    return bracket_close(c, stop);
+}
+
+int hmg_group_profile(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part* fft, const hmg_hod_part* hod,
+                      const hmg_power_batch_desc* prep) {
+    REQUIRE(c, "NULL ctx");
+    REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
+    REQUIRE(fft || hod || prep, "empty group");
+    REQUIRE((nm + 63) / 64 <= HOD_MAX_TILES, "nm too large");
+    PbPlan P;
+    if (prep && pb_plan(c, nz, nm, nk, prep, &P)) return 1;
+    ChainArgs C;
+    int one = 0;
+    if (chain_setup(nm, hod, prep ? &P : nullptr, &C, &one)) return 1;
+    int chain_done = 0;
+    if (fft && profile_fft_impl(c, nz, nm, nk, *fft, &C, one ? nz : 0, chain_lds_doubles(nm) * 8, &chain_done)) return 1;
+    if (one && !chain_done) {      // no rows to share a launch with (or a length the in-LDS transform does not take)
+        const RowsArgs none{};
+        if (launch_rows_group(c, nz, nm, C, nz, nullptr, none, nullptr, 0)) return 1;
+    }
+    if (prep && !P.code) {         // generic coefficient rows (register-hungry): a launch of their own
+        hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, P.PA.nblk), dim3(64), 0, c->stream, P.PA);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
 }
 
 int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const double* zs,

@@ -144,6 +144,11 @@ class HaloModel(Cosmology):
         self._dcache = {}
         self._pool = {}
         self._use_lanes = os.environ.get("HMG_LANES", "0") == "1"   # two-stream overlap
+        # Grouped launches: the launch-only stages of a pass are queued and issued when
+        # something consumes them, so that stages which do not depend on each other share a launch.
+        # HMG_NO_GROUPS=1 issues every stage as its own launch at call time (A/B timing, debugging).
+        self._groups = os.environ.get("HMG_NO_GROUPS", "0") != "1" and not self._use_lanes
+        self._stages = []
 
         # (name, name2) -> (state version, P1h, P2h): a fused launch yields both terms, so the
         # usual get_power_1halo(a,b) followed by get_power_2halo(a,b) streams the tensors once
@@ -295,6 +300,63 @@ class HaloModel(Cosmology):
     nzm = property(lambda self: self._lazy_host("nzm"))
     bh = property(lambda self: self._lazy_host("bh"))
 
+    # ------------------------------------------------------------------ grouped launches
+    # Which queued stage must not run before which (a stage kind appears at most once in the queue):
+    # the HOD reads n, b; the profile FFT reads the row parameters.
+    _RUNS_AFTER = {"hod": ("massfn",), "fft": ("rows",)}
+
+    def _queue(self, kind, part, keep=()):
+        """Queue a launch-only stage.  Anything that reads device state goes through the context, which
+        issues the queue first (Context.flush), so deferral is invisible to callers."""
+        pend = [st[0] for st in self._stages]
+        # same kind twice, a producer queued behind its own consumer (it would overwrite what the consumer
+        # still has to read), or the front of a new pass (it rewrites what every queued stage reads): issue
+        # what is queued first
+        if pend and (kind == "front" or kind in pend or any(kind in self._RUNS_AFTER.get(k, ()) for k in pend)):
+            self._ctx().flush()
+        self._stages.append((kind, part, keep))
+        self._ctx().defer(self)
+
+    def _flush(self, prep=None):
+        """Issue the queued stages as grouped launches: front (sigma^2 contraction | halo stage | HOD
+        occupations: inputs only), rows group (chain: massfn -> HOD sums | row parameters | NFW), profile
+        group (coefficient rows of the mass integrals `prep` describes | profile FFT rows).  Returns True if
+        `prep` was issued (hmg_power_batch_run then skips its preparation launch)."""
+        stages, self._stages = self._stages, []
+        st = {k: p for k, p, _ in stages}
+        if not st:
+            return False
+        ctx = self._ctx()
+        nz, nm, nk, nq = self._nz, self._nm, self._nk, getattr(self, "_nq", 0)
+        ref = lambda k: C.byref(st[k]) if k in st else None      # noqa: E731
+        x = os.environ.get("HMG_X", "")          # experiment switches (tuning only)
+        if "prep_alone" in x:
+            prep = None
+        hod_sums = False
+        if "front" in st:
+            occ = None
+            if "hod" in st:      # the occupation numbers need inputs only: they ride in the front launch ...
+                occ = nat.HodPart.from_buffer_copy(st["hod"])
+                occ.stage, st["hod"].stage = nat.HOD_OCCUPATIONS, nat.HOD_SUMS
+                hod_sums = True  # ... and n_gal, b_g, which need the n, b of this pass, in the profile group's chain
+            args = st.pop("front")
+            ctx.call_now("hmg_sigma2_halo_front", *args[:-1], C.byref(args[-1]), C.byref(occ) if occ is not None else None)
+        elif "hod" in st:        # no front to ride with: the HOD's own kernel (n, b are there already)
+            h = st.pop("hod")
+            ctx.call_now("hmg_hod", nz, nm, h.h_par, h.d_zs, h.d_ms, h.d_log10mstar_thresh, h.d_nzm, h.d_bh, h.d_wm,
+                         h.d_Nc, h.d_Ns, h.d_NsNsm1, h.d_NcNs, h.d_ngal, h.d_bg)
+        nfw_alone = st.pop("nfw") if "nfw_alone" in x and "nfw" in st else None
+        if any(k in st for k in ("massfn", "rows", "nfw")):
+            ctx.call_now("hmg_group_rows", nz, nm, nk, nq, ref("massfn"), None, ref("rows"), ref("nfw"))
+        if nfw_alone is not None:
+            ctx.call_now("hmg_nfw_analytic", nz, nm, nk, nfw_alone.d_cs, nfw_alone.d_rs, nfw_alone.d_zs, nfw_alone.d_ks,
+                         nfw_alone.d_nfw_series, nfw_alone.d_uk)
+        if "fft" in st or hod_sums:
+            ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), ref("hod") if hod_sums else None,
+                         C.byref(prep) if prep is not None else None)
+            return prep is not None
+        return False
+
     # ------------------------------------------------------------------ mass function
     def get_sigma2(self):
         """hmvec/hmvec.py:121-124 — evaluated by hmg_sigma2."""
@@ -382,7 +444,17 @@ class HaloModel(Cosmology):
                     float(self.p["Wkr_taylor_switch"]), C.byref(par), d_ms.ptr, d_lnm.ptr, nat.ptr(d_tz),
                     self._d_sigma2.ptr, self._d_nzm.ptr, self._d_bh.ptr)
         duffy = tuple(float(self.p[f"duffy_{k}_{sfx}"]) for k in ("A", "alpha", "beta"))
-        if not self._use_lanes:
+        if self._groups:
+            # front group: the contraction beside the halo stage (both need inputs only); the second stage of
+            # the contraction and n(z,m), b(z,m) are queued as the first link of the per-z chain
+            halo = nat.HaloStageArgs(self._d_zs().ptr, d_delta.ptr, d_rho.ptr, *duffy, float(self.h),
+                                     self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr, self._d_nfw_series.ptr,
+                                     d_drho1.ptr, 200.0, d_rhoc.ptr, m2.ptr, r2.ptr)
+            self._nq = int(d_kq.size)
+            self._queue("front", sig_args[:8] + (d_ms.ptr, halo))
+            self._queue("massfn", nat.MassFnPart(C.pointer(par), d_ms.ptr, d_lnm.ptr, nat.ptr(d_tz), self._d_sigma2.ptr,
+                                                 self._d_nzm.ptr, self._d_bh.ptr), keep=(par,))
+        elif not self._use_lanes:
             # one launch behind the contraction: mass function and halo stage side by side
             halo = nat.HaloStageArgs(self._d_zs().ptr, d_delta.ptr, d_rho.ptr, *duffy, float(self.h),
                                      self._d_cs.ptr, self._d_rvir.ptr, self._d_rs.ptr, self._d_nfw_series.ptr,
@@ -476,12 +548,16 @@ class HaloModel(Cosmology):
             # nconst is an int32 array: allocated as (nz*nm+1)//2 doubles, viewed as integers on read
             hint = (self._buf((key, "nconst"), ((nz * nm + 1) // 2,)), self._buf((key, "cconst"), (nz, nm)))
         amp, xc, alpha, expo = rowp
-        ctx.call("hmg_profile_fft", nz, nm, nk, int(nxs), step, d_xs.ptr, d_kts.ptr,
-                 nat.ptr(amp), nat.ptr(xc), nat.ptr(alpha), nat.ptr(expo),
-                 float(consts[0]), float(consts[1]), float(consts[2]), float(consts[3]), float(gamma),
-                 d_cmax.ptr, d_rss.ptr, self._d_zs().ptr, self._d_ks().ptr, int(do_mass_norm),
-                 nat.ptr(d_post), out.ptr, nat.ptr(hint[0] if hint else None), nat.ptr(hint[1] if hint else None),
-                 d_lx.ptr)
+        args = (int(nxs), step, d_xs.ptr, d_kts.ptr,
+                nat.ptr(amp), nat.ptr(xc), nat.ptr(alpha), nat.ptr(expo),
+                float(consts[0]), float(consts[1]), float(consts[2]), float(consts[3]), float(gamma),
+                d_cmax.ptr, d_rss.ptr, self._d_zs().ptr, self._d_ks().ptr, int(do_mass_norm),
+                nat.ptr(d_post), out.ptr, nat.ptr(hint[0] if hint else None), nat.ptr(hint[1] if hint else None),
+                d_lx.ptr)
+        if self._groups:
+            self._queue("fft", nat.ProfileFftPart(*args))
+        else:
+            ctx.call("hmg_profile_fft", nz, nm, nk, *args)
         return out, hint
 
     def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref):
@@ -501,6 +577,11 @@ class HaloModel(Cosmology):
             self._m200c_valid = True
             return outs
         m200c, r200c = self._m200c()
+        if self._groups:
+            self._queue("rows", nat.RowsPart(kind, m200c.ptr, r200c.ptr, self._d_rvir.ptr, self._d_zs().ptr, d_rhoc.ptr,
+                                             d_hz.ptr, fit, float(gamma), float(alpha_const), float(pref),
+                                             float(post_pref), *[o.ptr for o in outs]))
+            return outs
         ctx.call("hmg_profile_rowparams", kind, nz, nm, m200c.ptr, r200c.ptr, self._d_rvir.ptr,
                  self._d_zs().ptr, d_rhoc.ptr, d_hz.ptr, C.byref(fit), float(gamma), float(alpha_const),
                  float(pref), float(post_pref), *[o.ptr for o in outs])
@@ -592,8 +673,12 @@ class HaloModel(Cosmology):
                                           -1.0, self._d_cs, self._d_rs, True)
         else:
             out = self._buf(("uk", name), (nz, nm, nk))
-            ctx.call("hmg_nfw_analytic", nz, nm, nk, self._d_cs.ptr, self._d_rs.ptr, self._d_zs().ptr,
-                     self._d_ks().ptr, self._d_nfw_series.ptr, out.ptr)
+            if self._groups:
+                self._queue("nfw", nat.NfwPart(self._d_cs.ptr, self._d_rs.ptr, self._d_zs().ptr, self._d_ks().ptr,
+                                               self._d_nfw_series.ptr, out.ptr))
+            else:
+                ctx.call("hmg_nfw_analytic", nz, nm, nk, self._d_cs.ptr, self._d_rs.ptr, self._d_zs().ptr,
+                         self._d_ks().ptr, self._d_nfw_series.ptr, out.ptr)
         self.uk_profiles.set_dev(name, out, hint)
         return self.ks, _LazyArray(self.uk_profiles, name)
 
@@ -618,12 +703,17 @@ class HaloModel(Cosmology):
         elif not np.array_equal(cached[0], thr):
             # new thresholds go into the SAME device buffer (stream-ordered behind the launches that
             # read the old ones): nothing is freed, so nothing synchronises the other lanes
-            nat.check(ctx.lib.hmg_memcpy_h2d(ctx.handle, cached[1].ptr, thr.ctypes.data, thr.nbytes))
+            ctx.write(cached[1], thr)
             cached[0][...] = thr
         d_thr = cached[1]
         out = {k: self._buf((key, k), (nz, nm)) for k in ("Nc", "Ns", "NsNsm1", "NcNs")}
         out["ngal"], out["bg"] = self._buf((key, "ngal"), (nz,)), self._buf((key, "bg"), (nz,))
         d_wm, d_ms, d_zs = self._d_wm(), self._d_ms(), self._d_zs()     # (uploads, if any, before the lane switch)
+        if self._groups:
+            self._queue("hod", nat.HodPart(nat.HOD_ALL, C.pointer(par), d_zs.ptr, d_ms.ptr, d_thr.ptr, self._d_nzm.ptr,
+                                           self._d_bh.ptr, d_wm.ptr, out["Nc"].ptr, out["Ns"].ptr, out["NsNsm1"].ptr,
+                                           out["NcNs"].ptr, out["ngal"].ptr, out["bg"].ptr), keep=(par,))
+            return out
         ctx = self._aux()
         ctx.call("hmg_hod", nz, nm, C.byref(par), d_zs.ptr, d_ms.ptr, d_thr.ptr,
                  self._d_nzm.ptr, self._d_bh.ptr, d_wm.ptr, out["Nc"].ptr, out["Ns"].ptr,
@@ -806,14 +896,18 @@ class HaloModel(Cosmology):
         pb = (C.c_int * n)(*[u[1] for u in uniq])
         p1 = (C.c_void_p * n)(*[o1[i].ptr for i in first])
         p2 = (C.c_void_p * n)(*[o2[i].ptr for i in first])
-        ctx.call("hmg_power_batch", nz, nm, nk, len(names), tr, n, pa, pb, self._d_nzm.ptr, self._d_bh.ptr,
-                 self._d_ms().ptr, self._d_wm().ptr, self._d_ks().ptr, self._d_Pzk().ptr,
-                 self._rho_m0(), float(self.p["kstar_damping"]), p1, p2)
+        d_wm, d_Pzk = self._d_wm(), self._d_Pzk()         # (uploads, if any, before the queue is issued)
+        desc = nat.PowerBatchDesc(len(names), tr, n, pa, pb, self._d_nzm.ptr, self._d_bh.ptr, self._d_ms().ptr,
+                                  d_wm.ptr, self._d_ks().ptr, d_Pzk.ptr, self._rho_m0(),
+                                  float(self.p["kstar_damping"]), p1, p2)
+        # the coefficient rows of this batch ride in the profile group of the queued stages, if there is one
+        prepared = self._flush(prep=desc) if self._stages else False
+        ctx.call("hmg_power_batch_run", nz, nm, nk, C.byref(desc), nat.PB_PREPARED if prepared else 0)
         self._sync_point()
         for i, u in enumerate(alias):
             if first[u] != i:
-                ctx.lib.hmg_memcpy_d2d(ctx.handle, o1[i].ptr, o1[first[u]].ptr, o1[i].nbytes)
-                ctx.lib.hmg_memcpy_d2d(ctx.handle, o2[i].ptr, o2[first[u]].ptr, o2[i].nbytes)
+                ctx.call("hmg_memcpy_d2d", o1[i].ptr, o1[first[u]].ptr, o1[i].nbytes)
+                ctx.call("hmg_memcpy_d2d", o2[i].ptr, o2[first[u]].ptr, o2[i].nbytes)
         return o1, o2
 
     def spectra_block(self, pairs):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMG_ABI_VERSION 4
+#define HMG_ABI_VERSION 5
 
 typedef struct hmg_ctx hmg_ctx;
 
@@ -311,6 +311,87 @@ int hmg_power_batch(hmg_ctx* ctx, int nz, int nm, int nk, int ntr, const hmg_tra
                     const double* d_nzm, const double* d_bh, const double* d_ms, const double* d_wm,
                     const double* d_ks, const double* d_Pzk, double rho_m0, double kstar,
                     double* const* h_P1h, double* const* h_P2h);
+
+/* ---- grouped launches: independent stages of a pass as block ranges of ONE grid ---------------------
+ * The reference runs its stages one numpy expression after another (hmvec/hmvec.py:127-131, 188-250,
+ * 318-355, 357-460, 504-572); which of them do NOT depend on each other is a property of the model:
+ *     sigma^2 contraction, halo stage (c, r_vir, r_s, M_200c)          need inputs only
+ *     n(z,m), b(z,m)        <- sigma^2           HOD  <- n, b
+ *     NFW u(k), Battaglia row parameters <- halo stage    profile FFT rows <- row parameters
+ *     coefficient rows of the mass integrals <- n, b, HOD;   mass integrals <- those + the tensors
+ * A kernel boundary costs ~2 us and every per-(z,m) stage is latency-bound, so on a thin z-slab (a rank
+ * of an 8-GPU job: 4 redshifts) the small stages take a third of the step when each is its own launch.
+ * The three entry points below put independent stages into one launch each: short latency-bound
+ * workgroups first in the grid, the chip-filling ones behind them.  Every part is optional (NULL); a
+ * part has the arguments of its stand-alone entry point and produces the same bits.  Per-z CHAIN =
+ * HOD (or only its n_gal, b_g sums) -> coefficient rows, each link optional, one workgroup per redshift. */
+typedef struct {   /* second stage of the contraction + n, b: hmg_sigma2_massfn's arguments after taylor_switch */
+    const hmg_massfn_params* h_par;
+    const double *d_ms, *d_lnms, *d_tinker_z;
+    double *d_sigma2, *d_nzm, *d_bh;
+} hmg_massfn_part;
+#define HMG_HOD_ALL         0   /* occupation numbers and the n_gal, b_g sums (= hmg_hod) */
+#define HMG_HOD_OCCUPATIONS 1   /* <Nc>, <Ns>, <Ns(Ns-1)>, <NcNs> only: they depend on inputs alone (z, m, threshold) */
+#define HMG_HOD_SUMS        2   /* n_gal, b_g from stored occupations and n, b */
+typedef struct {   /* hmg_hod's arguments + which half */
+    int stage;
+    const hmg_hod_params* h_par;
+    const double *d_zs, *d_ms, *d_log10mstar_thresh, *d_nzm, *d_bh, *d_wm;
+    double *d_Nc, *d_Ns, *d_NsNsm1, *d_NcNs, *d_ngal, *d_bg;
+} hmg_hod_part;
+typedef struct {   /* hmg_profile_rowparams's arguments */
+    int kind;
+    const double *d_m200c, *d_r200c, *d_rvir, *d_zs, *d_rhocz, *d_hz;
+    double fit[9], gamma, alpha_const, amp_prefactor, post_prefactor;
+    double *d_amp, *d_xc, *d_alpha, *d_expo, *d_cmax, *d_rscale, *d_post;
+} hmg_rows_part;
+typedef struct {   /* hmg_nfw_analytic's arguments (d_nfw_series is required here) */
+    const double *d_cs, *d_rs, *d_zs, *d_ks, *d_nfw_series;
+    double* d_uk;
+} hmg_nfw_part;
+typedef struct {   /* hmg_profile_fft's arguments after nk */
+    int nxs;
+    double fft_step;
+    const double *d_xs, *d_kts, *d_amp, *d_xc, *d_alpha, *d_expo;
+    double amp_const, xc_const, alpha_const, expo_const, gamma;
+    const double *d_cmax, *d_rss, *d_zs, *d_ks;
+    int do_mass_norm;
+    const double* d_post;
+    double* d_out;
+    int* d_nconst;
+    double* d_cconst;
+    const double* d_logxs;
+} hmg_profile_fft_part;
+typedef struct {   /* hmg_power_batch's arguments after nk */
+    int ntr;
+    const hmg_tracer* h_tr;
+    int npairs;
+    const int *h_pair_a, *h_pair_b;
+    const double *d_nzm, *d_bh, *d_ms, *d_wm, *d_ks, *d_Pzk;
+    double rho_m0, kstar;
+    double* const* h_P1h;
+    double* const* h_P2h;
+} hmg_power_batch_desc;
+/* front: first stage of the sigma^2 contraction (hmg_sigma2_prepared's arguments; the partial sums stay
+ * in the context until a massfn part consumes them) beside the halo stage and, optionally, the occupation
+ * numbers of an HOD (stage HMG_HOD_OCCUPATIONS) - everything of a pass that needs inputs only.          */
+int hmg_sigma2_halo_front(hmg_ctx* ctx, int nz, int nm, int nq, const double* d_PT, const double* d_kq,
+                          const double* d_wq, const double* d_R, double taylor_switch,
+                          const double* d_ms, const hmg_halo_stage_args* h_halo,
+                          const hmg_hod_part* h_hod_occupations /* or NULL */);
+/* rows group: n(z,m), b(z,m) in 62-mass tiles | per-z chain (an HOD; not together with a massfn part, whose
+ * n, b it would need) | Battaglia row parameters | analytic NFW rows.  A massfn part needs the partial sums
+ * of the last hmg_sigma2_halo_front on this context with the same nz, nm, nq.                           */
+int hmg_group_rows(hmg_ctx* ctx, int nz, int nm, int nk, int nq, const hmg_massfn_part* h_massfn,
+                   const hmg_hod_part* h_hod, const hmg_rows_part* h_rows, const hmg_nfw_part* h_nfw);
+/* profile group: per-z chain (an HOD or its sums -> the coefficient rows of the batched mass integrals
+ * h_prep describes) | the rows of one hmg_profile_fft (lengths its in-LDS transform takes; otherwise the
+ * parts are issued one after the other).  After a call with h_prep, hmg_power_batch_run(...,
+ * HMG_PB_PREPARED) with the SAME description runs the mass integrals without their preparation launch. */
+int hmg_group_profile(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_profile_fft_part* h_fft,
+                      const hmg_hod_part* h_hod, const hmg_power_batch_desc* h_prep);
+#define HMG_PB_PREPARED 1
+int hmg_power_batch_run(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_power_batch_desc* h_desc, int flags);
 
 /* ---- N1: Limber projection ------------------------------------------------------------------
  * Replaces limber_integral (hmvec/cosmology.py:867-904): for every multipole,

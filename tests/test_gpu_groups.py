@@ -1,0 +1,178 @@
+"""Grouped launches (include/hmgrid.h "grouped launches"): independent stages of a pass
+as block ranges of one grid.  Every role runs the device function of its stand-alone kernel, so the results
+must equal the one-launch-per-stage path BIT FOR BIT - state arrays, tensors, hints and spectra - on full
+grids, thin z-slabs, ragged mass grids, both mass functions, and whatever order the stages are queued in."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("nfw", "electron"), ("g", "nfw"), ("g", "electron")]
+
+
+def build(monkeypatch, grouped, zs, ms, ks, nxs=1000, mass_function="sheth-torman", pressure=False, corr="max"):
+    import hmvec_amd as hm
+    monkeypatch.setenv("HMG_NO_GROUPS", "0" if grouped else "1")
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic", mass_function=mass_function)
+    assert h._groups == grouped
+    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=nxs)
+    if pressure:
+        h.add_battaglia_pres_profile("y", family="pres", xmax=5, nxs=nxs)
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, corr=corr)
+    return h
+
+
+def state(h, pairs=PAIRS):
+    out = {"sigma2": h.sigma2, "nzm": h.nzm, "bh": h.bh, "cs": h._d_cs.numpy(), "rvir": h._d_rvir.numpy(),
+           "uk_nfw": h.uk_profiles["nfw"], "uk_e": h.uk_profiles["electron"]}
+    for k in ("Nc", "Ns", "NsNsm1", "NcNs", "ngal", "bg"):
+        out["hod_" + k] = h.hods["g"][k]
+    hint = h.uk_profiles.hint("electron")
+    if hint[0] is not None:
+        out["nconst"] = hint[0].numpy().view(np.int32)[:h.zs.size * h.ms.size]
+        out["cconst"] = hint[1].numpy()
+    return out
+
+
+def assert_same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("nz,nm,nk,mf", [(3, 48, 96, "sheth-torman"), (4, 200, 257, "tinker"), (5, 77, 130, "sheth-torman"),
+                                         (2, 300, 64, "sheth-torman")])
+def test_grouped_pass_equals_one_launch_per_stage(monkeypatch, nz, nm, nk, mf):
+    zs = np.linspace(0.1, 2.9, nz)
+    ms = np.geomspace(2e10, 1e17, nm)
+    ks = np.geomspace(1e-4, 100, nk)
+    e = build(monkeypatch, False, zs, ms, ks, mass_function=mf)
+    e1, e2 = e.power_device_batch(PAIRS)
+    g = build(monkeypatch, True, zs, ms, ks, mass_function=mf)
+    # spectra first: on the grouped model this is what issues the queue (chain + rows + NFW, then the
+    # coefficient rows of the batch beside the profile FFT)
+    assert len(g._stages) > 0
+    g1, g2 = g.power_device_batch(PAIRS)
+    assert g._stages == []
+    for p, a, b, c, d in zip(PAIRS, g1, g2, e1, e2):
+        assert np.array_equal(a.numpy(), c.numpy()), p
+        assert np.array_equal(b.numpy(), d.numpy()), p
+    assert_same(state(g), state(e))
+
+
+@pytest.mark.parametrize("nz,nm", [(3, 64), (20, 100), (2, 96), (8, 128), (17, 513)])
+def test_hod_right_behind_the_constructor_rides_with_the_front(monkeypatch, nz, nm):
+    """Constructor + add_hod with nothing read in between: one front launch (contraction | halo stage | HOD
+    occupations) and one rows group whose chain is mass function -> n_gal, b_g sums.  On fresh buffers, so that
+    a sum taken from stale memory cannot pass (a repeated pass would hide it: the stale values are the right ones)."""
+    import hmvec_amd as hm
+    zs = np.linspace(0.01, 2.0, nz)
+    ms = np.geomspace(2e10, 1e17, nm)
+    ks = np.geomspace(1e-4, 100, 70)
+    thr = 10 ** 10.5 + zs * 0.0
+    out = []
+    for grouped in (False, True):
+        monkeypatch.setenv("HMG_NO_GROUPS", "0" if grouped else "1")
+        h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+        h.add_hod("g", mthresh=thr)
+        if grouped:
+            assert [s[0] for s in h._stages] == ["front", "massfn", "nfw", "hod"]
+        out.append({k: h.hods["g"][k] for k in ("ngal", "bg", "Nc", "Ns", "NsNsm1", "NcNs")} | {"nzm": h.nzm, "bh": h.bh})
+    assert_same(out[0], out[1])
+    assert np.all(out[1]["ngal"] > 0)
+
+
+def test_reads_issue_the_queue_in_any_order(monkeypatch):
+    """Reading any piece of state first (instead of asking for spectra) must give the same numbers."""
+    zs = np.array([0.0, 0.6, 1.5, 3.0])
+    ms = np.geomspace(2e10, 1e17, 64)
+    ks = np.geomspace(1e-4, 100, 80)
+    e = build(monkeypatch, False, zs, ms, ks, pressure=True, corr="min")
+    want = state(e)
+    want_y = e.pk_profiles["y"]
+    for first in ("hod_ngal", "uk_e", "nzm", "uk_nfw", "cs"):
+        g = build(monkeypatch, True, zs, ms, ks, pressure=True, corr="min")
+        got_first = state(g)[first] if first != "hod_ngal" else g.hods["g"]["ngal"]
+        assert np.array_equal(got_first, want[first])
+        assert_same(state(g), want)
+        assert np.array_equal(g.pk_profiles["y"], want_y)
+        for a, b in (("y", "y"), ("g", "y"), ("nfw", "y")):
+            assert np.array_equal(g.get_power(a, b), e.get_power(a, b)), (a, b)
+
+
+def test_requeueing_a_stage_issues_the_earlier_one_first(monkeypatch):
+    """The same stage twice (a pass repeated without reading anything) and a producer queued behind its consumer."""
+    zs = np.array([0.3, 1.1])
+    ms = np.geomspace(2e10, 1e17, 96)
+    ks = np.geomspace(1e-4, 100, 64)
+    g = build(monkeypatch, True, zs, ms, ks)
+    e = build(monkeypatch, False, zs, ms, ks)
+    for h in (g, e):
+        for _ in range(2):
+            h.init_mass_function(ms)
+            h.add_nfw_profile("nfw", ignore_existing=True)
+            h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000, ignore_existing=True)
+            h.add_hod("g", mthresh=10 ** 10.8 + zs * 0.0, ignore_existing=True)
+        # a second mass function behind a queued HOD: the HOD must still see the n, b of before
+        h.add_hod("g2", mthresh=10 ** 11.0 + zs * 0.0)
+        h.init_mass_function(ms)
+    assert_same(state(g), state(e))
+    assert np.array_equal(g.hods["g2"]["ngal"], e.hods["g2"]["ngal"])
+    assert np.array_equal(g.get_power("g", "g2"), e.get_power("g", "g2"))
+
+
+def test_a_captured_pass_with_groups_replays_identically(monkeypatch):
+    zs = np.linspace(0.2, 2.0, 4)
+    ms = np.geomspace(2e10, 1e17, 128)
+    ks = np.geomspace(1e-4, 100, 256)
+    g = build(monkeypatch, True, zs, ms, ks)
+    e = build(monkeypatch, False, zs, ms, ks)
+    ctx = g._ctx()
+    blk = g.spectra_block(PAIRS)
+    thr = 10 ** 10.5 + zs * 0.0
+
+    def one_pass():
+        g.init_mass_function(ms)
+        g.add_nfw_profile("nfw", ignore_existing=True)
+        g.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000, ignore_existing=True)
+        g.add_hod("g", mthresh=thr, ignore_existing=True)
+        blk.compute()
+
+    one_pass()
+    ctx.sync()
+    gid = ctx.capture(one_pass)
+    assert g._stages == []
+    for _ in range(3):
+        ctx.replay(gid)
+    got = blk.fetch()
+    e1, e2 = e.power_device_batch(PAIRS)
+    for p, a, b in zip(PAIRS, e1, e2):
+        assert np.array_equal(got[p][0], a.numpy()), p
+        assert np.array_equal(got[p][1], b.numpy()), p
+
+
+def test_group_entry_points_reject_bad_arguments():
+    from hmvec_amd import _native as nat
+    ctx = nat.default_context()
+    lib = ctx.lib
+    assert lib.hmg_group_rows(ctx.handle, 2, 8, 8, 16, None, None, None, None) != 0
+    assert b"empty group" in lib.hmg_last_error()
+    d = ctx.empty((64,))
+    par = nat.MassFnParams(mode=0, deltac=1.686, st_A=0.3, st_a=0.7, st_p=0.3, rho_m0=1.0, lnm_uniform=0, lnm_step=0.0)
+    mf = nat.MassFnPart(C.pointer(par), d.ptr, d.ptr, None, d.ptr, d.ptr, d.ptr)
+    # no contraction of this shape has left partial sums in the context
+    assert lib.hmg_group_rows(ctx.handle, 3, 7, 8, 12345, C.byref(mf), None, None, None) != 0
+    assert b"hmg_sigma2_halo_front" in lib.hmg_last_error()
+    nfw = nat.NfwPart(d.ptr, d.ptr, d.ptr, d.ptr, None, d.ptr)
+    assert lib.hmg_group_rows(ctx.handle, 2, 4, 8, 16, None, None, None, C.byref(nfw)) != 0
+    assert b"NFW part" in lib.hmg_last_error()
+    hp = nat.HodParams(0.2, 1.0, 10.0, 1.0, 1.0, 1.0, 0)
+    hod = nat.HodPart(nat.HOD_ALL, C.pointer(hp), *([d.ptr] * 12))
+    assert lib.hmg_group_rows(ctx.handle, 3, 7, 8, 16, C.byref(mf), C.byref(hod), None, None) != 0
+    assert b"cannot share its launch" in lib.hmg_last_error()
+    assert lib.hmg_group_rows(ctx.handle, 3, 7, 8, 16, None, C.byref(hod), None, None) != 0
+    assert b"sums of an HOD" in lib.hmg_last_error()
+    assert lib.hmg_group_profile(ctx.handle, 2, 4, 8, None, None, None) != 0
+    assert lib.hmg_power_batch_run(ctx.handle, 2, 4, 8, None, 0) != 0
