@@ -637,10 +637,9 @@ __global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, doubl
 }
 
 // ktile = k values per workgroup (a multiple of the block size)
-// 6 waves/SIMD (80 VGPRs, a few spills in the rare closed-form path) beats the 4-5 the compiler picks
-// on its own and the 8 that spill in the hot paths: 0.167 / 0.160 / 0.179 ms (MI355X, Config 3).
+// 46 VGPRs, no scratch (with machine LICM off: see the Makefile); the bound only keeps it under 64.
 #ifndef HMG_NFW_OCC
-#define HMG_NFW_OCC 6
+#define HMG_NFW_OCC 8
 #endif
 struct NfwArgs {
     const SiciTable* T;
@@ -2186,30 +2185,30 @@ struct RowsArgs {
     double gamma, alpha_const, pref, post_pref;
     RowOut O;
 };
-__device__ __attribute__((noinline)) void rows_block(const RowsArgs HMG_KERNARG* rp_in, int b_in) {
-    const RowsArgs Rw = kernarg_load(uniform_kernarg(rp_in));
-    const int idx = __builtin_amdgcn_readfirstlane(b_in) * 256 + threadIdx.x;
+__device__ __forceinline__ void rows_block(const RowsArgs& Rw, int b) {
+    const int idx = b * 256 + threadIdx.x;
     if (idx < Rw.n) {
         const int z = idx / Rw.nm;
         rowparams_body(Rw.kind, idx, Rw.m200[idx], Rw.r200[idx], Rw.rvir[idx], 1.0 + Rw.zs[z], Rw.rhoc[z],
                        Rw.hz ? Rw.hz[z] : 1.0, Rw.F, Rw.gamma, Rw.alpha_const, Rw.pref, Rw.post_pref, Rw.O);
     }
 }
-__device__ __attribute__((noinline)) void massfn_block(const SigmaMassFnArgs HMG_KERNARG* sp_in, int b_in, int ntile) {
+__device__ __forceinline__ void massfn_block(const SigmaMassFnArgs& S, int b, int nt) {
     __shared__ double red[4 * 64];
     __shared__ double sig[64];
-    const SigmaMassFnArgs S = kernarg_load(uniform_kernarg(sp_in));
-    const int b = __builtin_amdgcn_readfirstlane(b_in), nt = __builtin_amdgcn_readfirstlane(ntile);
     sigma2_massfn_tile(S, b / nt, b - (b / nt) * nt, red, sig);
 }
-struct RowsGroupArgs {       // the FIRST kernel parameter, so that the cold roles can address their part of it in place
+struct RowsGroupArgs {
     ChainArgs C;
     RowsArgs Rw;
     SigmaMassFnArgs S;
     int nchain, nrowblk, nmfblk, mf_ntile;
 };
 // (the NFW role's pointers are kernel parameters of their own: see nfw_rows)
-__global__ __launch_bounds__(256, HMG_NFW_OCC) void rows_group_kernel(RowsGroupArgs G, const SiciTable* __restrict__ T,
+#ifndef HMG_ROWS_OCC
+#define HMG_ROWS_OCC 7
+#endif
+__global__ __launch_bounds__(256, HMG_ROWS_OCC) void rows_group_kernel(RowsGroupArgs G, const SiciTable* __restrict__ T,
                                                                       const double* __restrict__ acoef, int ktile, int nm,
                                                                       int nk, const double* __restrict__ cs,
                                                                       const double* __restrict__ rss,
@@ -2217,7 +2216,6 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void rows_group_kernel(RowsGroupA
                                                                       const double* __restrict__ ks,
                                                                       double* __restrict__ uk) {
     extern __shared__ double lds[];
-    const RowsGroupArgs HMG_KERNARG* kp = (const RowsGroupArgs HMG_KERNARG*)__builtin_amdgcn_kernarg_segment_ptr();
     int b = blockIdx.x;
     if (b < G.nchain) {
         chain_row<256>(G.C, b, lds);
@@ -2225,12 +2223,12 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void rows_group_kernel(RowsGroupA
     }
     b -= G.nchain;
     if (b < G.nmfblk) {
-        massfn_block(&kp->S, b, G.mf_ntile);
+        massfn_block(G.S, b, G.mf_ntile);
         return;
     }
     b -= G.nmfblk;
     if (b < G.nrowblk) {
-        rows_block(&kp->Rw, b);
+        rows_block(G.Rw, b);
         return;
     }
     nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, b - G.nrowblk, 256);
