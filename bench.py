@@ -53,45 +53,79 @@ def workload(nz=32, nm=512, nk=4096):
 # ------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` with no rank environment
 # ------------------------------------------------------------------------------------------------
-def spawn_ranks(args, argv):
+def spawn_ranks(args, argv, cmd=None):
     """Start one fresh process per GPU with RANK/LOCAL_RANK/WORLD_SIZE set, relay rank 0's stdout.
     The parent makes no GPU call (it does not even import the package), so nothing is re-executed
-    from a process that has initialised the device."""
+    from a process that has initialised the device.  The ranks are SUPERVISED: all of them are polled,
+    the first non-zero exit terminates the others (a rank that dies before the communicator exists would
+    otherwise leave its peers waiting in ncclCommInitRank or at the rendezvous file), an overall deadline
+    bounds the launch, and the failing rank's stderr tail is reported.  Returns the exit code."""
     import socket
+    import tempfile
+    import threading
     n = args.gpus
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run"]
+    if cmd is None:            # (tests hand in another rank program to exercise the supervision)
+        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run"]
+    deadline_s = float(os.environ.get("HMG_LAUNCH_DEADLINE", "540"))      # under the driver's 600 s
     envs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HMG_LAUNCH_TAG=f"{port}_{os.getpid()}")
         # dmabuf IPC is the only mode the host driver of this pool supports; RCCL's peer set-up needs it
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a supervised rank never needs to wait for the id longer than the slowest first library page-in
+        env.setdefault("HMG_RDZV_TIMEOUT", "240")
         envs.append(env)
     if args.dry_run:
         keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HMG_LAUNCH_TAG",
-                "HSA_ENABLE_IPC_MODE_LEGACY")
-        print(json.dumps({"dry_run": True, "n_ranks": n, "cmd": cmd,
+                "HSA_ENABLE_IPC_MODE_LEGACY", "HMG_RDZV_TIMEOUT")
+        print(json.dumps({"dry_run": True, "n_ranks": n, "cmd": cmd, "deadline_s": deadline_s,
                           "rank_env": [{k: e[k] for k in keys} for e in envs]}))
         return 0
-    procs = [subprocess.Popen(cmd, env=envs[r], stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL)
-             for r in range(n)]
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if os.environ.get("HMG_COMM") == "host-rehearsal":      # the rehearsal transport's last-round files
-        import glob
-        pat = f"hmg_reh_{port}_{os.getpid()}_w{n}_pp{os.getpid()}_s*"
-        for f in glob.glob(os.path.join(os.environ.get("HMG_REHEARSAL_DIR", "/dev/shm"), pat)):
+    errs = [tempfile.TemporaryFile() for _ in range(n)]
+    procs = [subprocess.Popen(cmd, env=envs[r], stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                              stderr=errs[r]) for r in range(n)]
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t_end = time.monotonic() + deadline_s
+    failed, why = None, ""
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed, why = bad[0], f"rank {bad[0]} exited with code {rcs[bad[0]]}"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > t_end:
+            failed, why = -1, f"launch exceeded its deadline of {deadline_s:.0f} s"
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
             try:
-                os.remove(f)
-            except OSError:
-                pass
-    sys.stdout.write(out0)
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    sys.stdout.write((out0[0] if out0 else b"").decode())
     sys.stdout.flush()
-    if any(rcs):
-        sys.stderr.write(f"bench.py launcher: rank exit codes {rcs}\n")
+    if failed is not None:
+        rcs = [p.returncode for p in procs]
+        sys.stderr.write(f"bench.py launcher: {why}; rank exit codes {rcs}\n")
+        show = failed if failed >= 0 else 0
+        errs[show].seek(0)
+        tail = errs[show].read().decode(errors="replace").strip().splitlines()[-15:]
+        sys.stderr.write(f"---- stderr tail of rank {show} ----\n" + "\n".join(tail) + "\n")
         return 1
     return 0
 
@@ -261,8 +295,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if os.environ.get("HMG_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0       # functional rehearsal of the N > 1 path on a one-GPU box (timings meaningless)
     args.gpus = world
     # Multi-process GPU work on this platform needs dmabuf IPC (the task environment exports it; keep it
     # if a launcher dropped it).  Set here, in the benchmark, before anything loads the HIP runtime -
@@ -289,15 +321,8 @@ def main():
     ctx = nat.Context(local_rank)
     tag = os.environ.get("HMG_LAUNCH_TAG") or \
         f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'solo')}"
-    transport = os.environ.get("HMG_COMM", "rccl")
-    if transport == "host-rehearsal" and world > 1:
-        # functional rehearsal of the N > 1 flow without RCCL (e.g. two ranks on one device): labelled in the line
-        from hmvec_amd.dist import HostRehearsalComm
-        comm = HostRehearsalComm(ctx, rank, world, tag)
-    else:
-        transport = "rccl"
-        comm = RcclComm(ctx, rank, world, tag)
-    rccl_rank, rccl_ranks = comm.info()
+    comm = RcclComm(ctx, rank, world, tag)
+    rccl_rank, rccl_ranks = comm.info()          # (None, None) for a single rank: no communicator is created
 
     mthr = 10 ** 10.5 + zloc * 0.0
     h = hm.HaloModel(zloc, ks, ms=ms, accuracy="low", engine="analytic", ctx=ctx)
@@ -531,7 +556,7 @@ def main():
     out = {
         "metric": "(z,m,k) grid-points/sec for P_1h+P_2h",
         "value": pts * K / dt_max, "unit": "grid-points/s",
-        "n_gpus": world, "rccl_ranks": rccl_ranks if transport == "rccl" else 0, "transport": transport, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "transport": "rccl" if rccl_ranks else None, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
         "host_issue_ms_per_step": t_issue / K * 1e3, "preconditioning_steps": PRECONDITION,
         "launch_mode": ("hip-graph replay" if use_graph else "eager launches") + (", lanes" if args.lanes else ""),
         "kernel_events": f"HIP events around the three large kernels on every {BRACKET_EVERY}th timed step"

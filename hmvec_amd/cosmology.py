@@ -428,6 +428,30 @@ class Cosmology(object):
             return np.sqrt(r[0]), r[1], r[2]
         return np.sqrt(r)
 
+    # Newton's constant [Mpc^3 / Msun / s^2] and the speed of light [Mpc / s] to the four digits the
+    # reference hard-codes (hmvec/cosmology.py:96-97): parity needs these numbers, not better ones
+    _G_MPC_MSUN_S, _C_MPC_S = 4.517e-48, 9.716e-15
+
+    def sigma_crit(self, zlens, zsource):
+        """Critical surface density c^2 D_s / (4 pi G D_d D_ds) [Msun / Mpc^2] of lenses at ``zlens`` (array)
+        for a source plane at ``zsource`` (hmvec/cosmology.py:95-101).  Off the grid path: three distance
+        look-ups per lens on the host."""
+        zl = np.atleast_1d(np.asarray(zlens, dtype=np.float64))
+        d_lens = self.angular_diameter_distance(zl)
+        d_src = self.angular_diameter_distance(zsource)
+        d_ls = np.array([self.angular_diameter_distance(z, zsource) for z in zl]).reshape(zl.shape)
+        return (self._C_MPC_S ** 2 / (4.0 * np.pi * self._G_MPC_MSUN_S)) * d_src / (d_lens * d_ls)
+
+    def bias_fnl(self, bg, fnl, z, ks, deltac=1.42):
+        """Scale-dependent bias of local primordial non-Gaussianity, b(k) = b_g + f_NL beta / alpha(k)
+        with beta = 2 delta_c (b_g - 1) and alpha = 2 k^2 T(k) D(a) / (3 Omega_m H_0^2)
+        (hmvec/cosmology.py:132-136; examples/fnl.py): Eisenstein-Hu transfer function with wiggles, growth
+        normalised to a in matter domination, H_0 in 1/Mpc."""
+        ks = np.asarray(ks, dtype=np.float64)
+        growth = self.D_growth(1.0 / (1.0 + z), type="anorm", exact=False)
+        poisson = 2.0 * ks ** 2.0 * self.Tk(ks, type="eisenhu_osc") / (3.0 * self.omm0 * self.h_of_z(0) ** 2.0)
+        return bg + fnl * (2.0 * deltac * (bg - 1.0)) / (poisson * growth)
+
     def P_mm_linear(self, zs, ks):
         """Placeholder in the reference too (hmvec/cosmology.py:104-105: ``pass``)."""
         return None

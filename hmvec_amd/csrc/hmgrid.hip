@@ -118,6 +118,8 @@ struct hmg_ctx {
     bool lanes_dirty = false;                      // work was enqueued on a lane other than 0 since the last sync
     // captured steps (hmg_graph_*)
     bool capturing = false;
+    std::vector<void*> freed_in_capture;           // hmg_free calls that arrived during a capture ...
+    std::map<int, std::vector<void*>> graph_blocks; // ... stay with the graph that may use them until it is destroyed
     std::map<int, hipGraphExec_t> graphs;
     int next_graph_id = 1;
     hmg_ctx() { for (auto& b : bracket) b[0] = b[1] = -1; }
@@ -2467,6 +2469,11 @@ __global__ __launch_bounds__(256) void fn2d_kernel(FnArgs A) {
     case HMG_FN_LINCOMB3:
         y = par[0] * X(0) + par[1] * X(1) + par[2] * X(2);
         break;
+    case HMG_FN_BRUTE_INTEGRAND: {
+        const double r = X(0), k = X(2);
+        y = 4.0 * M_PI * r * sin(r * k) * X(1) / k;
+        break;
+    }
     }
     A.out[idx] = y;
 }
@@ -2617,6 +2624,9 @@ int hmg_ctx_destroy(hmg_ctx* c) {
     }
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : c->graph_blocks)
+        for (void* p : kv.second) (void)hipFree(p);
+    for (void* p : c->freed_in_capture) (void)hipFree(p);
     if (c->d_barrier) (void)hipFree(c->d_barrier);
     if (c->d_sici) (void)hipFree(c->d_sici);
     if (c->up_ring) {
@@ -2642,6 +2652,10 @@ int hmg_ctx_destroy(hmg_ctx* c) {
 int hmg_malloc(hmg_ctx* c, size_t bytes, void** d_out) {
     REQUIRE(c && d_out, "NULL argument");
     if (!bytes) bytes = 8;
+    // No allocation at all inside a captured step, not even out of the free list: the address would be baked
+    // into the graph, the block would go back to the list when its owner dies and be handed to somebody else,
+    // and every later replay would write into memory it no longer owns.
+    REQUIRE(!c->capturing, "device allocation inside a captured step: run the step once eagerly first");
     auto it = c->free_blocks.find(bytes);
     if (it != c->free_blocks.end()) {
         *d_out = it->second;
@@ -2649,7 +2663,6 @@ int hmg_malloc(hmg_ctx* c, size_t bytes, void** d_out) {
         c->free_blocks.erase(it);
         return 0;
     }
-    REQUIRE(!c->capturing, "device allocation inside a captured step: run the step once eagerly first");
     HIP_TRY(hipSetDevice(c->device));
     hipError_t e = hipMalloc(d_out, bytes);
     if (e != hipSuccess && !c->free_blocks.empty()) {      // give the cache back and retry once
@@ -2666,9 +2679,12 @@ int hmg_malloc(hmg_ctx* c, size_t bytes, void** d_out) {
 int hmg_free(hmg_ctx* c, void* p) {
     REQUIRE(c, "NULL ctx");
     if (!p) return 0;
-    REQUIRE(!c->capturing, "hmg_free inside a captured step");
     auto it = c->block_bytes.find(p);
     REQUIRE(it != c->block_bytes.end(), "pointer was not allocated by hmg_malloc of this context");
+    if (c->capturing) {      // deferred, not dropped: the block joins the free list when the capture ends
+        c->freed_in_capture.push_back(p);
+        return 0;
+    }
     if (c->lanes_dirty && sync_all(c)) return 1;
     const size_t bytes = it->second;
     if (c->cached_bytes + bytes <= FREE_CACHE_LIMIT) {
@@ -2837,6 +2853,11 @@ int hmg_graph_begin(hmg_ctx* c) {
     c->capturing = true;
     return 0;
 }
+static void release_deferred_frees(hmg_ctx* c) {
+    std::vector<void*> v;
+    v.swap(c->freed_in_capture);
+    for (void* p : v) (void)hmg_free(c, p);
+}
 int hmg_graph_end(hmg_ctx* c, int* id) {
     REQUIRE(c && id, "NULL argument");
     REQUIRE(c->capturing, "no capture in progress");
@@ -2848,15 +2869,21 @@ int hmg_graph_end(hmg_ctx* c, int* id) {
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
+    if (e != hipSuccess) release_deferred_frees(c);       // no graph: nothing can refer to them any more
     HIP_TRY(e);
     *id = c->next_graph_id++;
     c->graphs[*id] = ge;
+    // A block handed back while the capture ran was allocated before it (allocation inside a capture is
+    // refused) and may be an operand of a captured launch: it stays out of the free list as long as the
+    // graph can be replayed.
+    c->graph_blocks[*id].swap(c->freed_in_capture);
     return 0;
 }
 int hmg_graph_abort(hmg_ctx* c) {      // leave capture mode after a failed call inside a capture
     REQUIRE(c, "NULL ctx");
     if (!c->capturing) return 0;
     c->capturing = false;
+    release_deferred_frees(c);
     c->lane = 0;
     c->stream = c->lanes[0];
     hipGraph_t g = nullptr;
@@ -2880,6 +2907,11 @@ int hmg_graph_destroy(hmg_ctx* c, int id) {
     if (sync_all(c)) return 1;
     HIP_TRY(hipGraphExecDestroy(it->second));
     c->graphs.erase(it);
+    auto gb = c->graph_blocks.find(id);
+    if (gb != c->graph_blocks.end()) {
+        for (void* p : gb->second) (void)hmg_free(c, p);
+        c->graph_blocks.erase(gb);
+    }
     return 0;
 }
 
@@ -3860,8 +3892,8 @@ int hmg_limber(hmg_ctx* c, int nells, const double* ells, int nz, int nk, const 
 // ---- function mirrors ------------------------------------------------------------------------
 int hmg_fn2d(hmg_ctx* c, int op, int rows, int cols, int nin, const double* const* in, const int* sr,
              const int* sc, const double* par, int npar, double* out) {
-    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4, 2, 3, 2};
-    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4, 1, 3, 10};
+    static const int need_in[HMG_FN_COUNT] = {1, 4, 2, 2, 4, 1, 2, 2, 1, 3, 3, 2, 2, 4, 4, 5, 4, 3, 1, 4, 4, 1, 4, 2, 3, 2, 3};
+    static const int need_par[HMG_FN_COUNT] = {1, 3, 0, 1, 1, 2, 1, 1, 0, 0, 0, 4, 3, 12, 12, 14, 14, 0, 0, 0, 0, 4, 4, 1, 3, 10, 0};
     REQUIRE(c && in && sr && sc && out, "NULL argument");
     REQUIRE(op >= 0 && op < HMG_FN_COUNT, "unknown function id");
     REQUIRE(rows > 0 && cols > 0, "empty grid");

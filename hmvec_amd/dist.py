@@ -37,13 +37,37 @@ def rendezvous_path(tag, world):
     return os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), name)
 
 
+def _parent_start_ticks():
+    """Start time of the parent process in clock ticks since boot (field 22 of /proc/<pid>/stat): together
+    with its PID it names ONE launcher for the lifetime of the machine, whatever the wall clock does."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat", "rb") as f:
+            return f.read().rsplit(b")", 1)[1].split()[19].decode()
+    except (OSError, IndexError):
+        return "0"
+
+
+def launch_nonce(tag, world):
+    """What every rank of THIS launch knows and no earlier launch could have written: tag, world size, the
+    launcher's PID and start time, the elastic restart count.  Stored in the rendezvous file in front of the
+    id and compared by the readers - a leftover of a crashed earlier launch that happens to have the same
+    name (same port, same run id, a recycled PID) is rejected by content, not by how old it looks."""
+    restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    text = f"{tag}|w{world}|pp{os.getppid()}@{_parent_start_ticks()}|r{restart}"
+    return text.encode()[:NONCE_BYTES].ljust(NONCE_BYTES, b"\0")
+
+
+NONCE_BYTES = 96
+
+
 def exchange_unique_id(ctx, rank, world, tag):
     """Rank 0 creates the RCCL unique id and publishes it through a file; the other ranks
     of the node poll for it.  (One node only: SURVEY 8e; the id is 128 opaque bytes.)
     Rank 0 removes any leftover of an earlier launch first and creates the file exclusively
-    with mode 0600; the others accept only a file written after they started looking (minus a
-    clock-skew allowance), so the id of a crashed earlier launch is never picked up."""
+    with mode 0600; the file carries the launch nonce in front of the id and the other ranks accept
+    only a file with THEIR nonce, so the id of a crashed earlier launch is never picked up."""
     path = rendezvous_path(tag, world)
+    nonce = launch_nonce(tag, world)
     buf = C.create_string_buffer(nat.COMM_ID_BYTES)
     if rank == 0:
         nat.check(ctx.lib.hmg_comm_unique_id(buf))
@@ -55,26 +79,23 @@ def exchange_unique_id(ctx, rank, world, tag):
                 pass
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(buf.raw)
+            f.write(nonce + buf.raw)
         os.replace(tmp, path)
         return buf
-    t_start = _PROCESS_START - float(os.environ.get("HMG_RDZV_SKEW", "5"))
-    deadline = time.time() + float(os.environ.get("HMG_RDZV_TIMEOUT", "600"))   # first library page-in on a fresh box can take minutes
+    # (the first library page-in on a fresh box can take minutes; a launcher that supervises its ranks sets
+    # a shorter limit: bench.py)
+    deadline = time.time() + float(os.environ.get("HMG_RDZV_TIMEOUT", "600"))
     while time.time() < deadline:
         try:
-            fresh = os.path.getmtime(path) >= t_start
             with open(path, "rb") as f:
                 raw = f.read()
-            if fresh and len(raw) == nat.COMM_ID_BYTES:
-                buf.raw = raw
+            if len(raw) == NONCE_BYTES + nat.COMM_ID_BYTES and raw[:NONCE_BYTES] == nonce:
+                buf.raw = raw[NONCE_BYTES:]
                 return buf
         except FileNotFoundError:
             pass
         time.sleep(0.01)
-    raise TimeoutError(f"no RCCL unique id at {path}")
-
-
-_PROCESS_START = time.time()
+    raise TimeoutError(f"no RCCL unique id of this launch at {path}")
 
 
 class RcclComm:
@@ -116,7 +137,10 @@ class RcclComm:
         self.ctx.call("hmg_comm_barrier")
 
     def info(self):
-        """(rank, nranks) as RCCL itself reports them (1 rank without a communicator)."""
+        """(rank, nranks) as RCCL itself reports them; (None, None) when no communicator was created
+        (a single rank needs none)."""
+        if not self._inited:
+            return None, None
         r, n = C.c_int(), C.c_int()
         self.ctx.call("hmg_comm_info", C.byref(r), C.byref(n))
         return r.value, n.value
@@ -129,81 +153,6 @@ class RcclComm:
                     os.remove(self._path)
                 except OSError:
                     pass
-
-
-class HostRehearsalComm:
-    """Stand-in communicator for REHEARSING the N > 1 flow where RCCL cannot run: RCCL refuses two ranks on
-    one device, so on a one-GPU box ``bench.py --gpus 2`` stops at ncclCommInitRank.  With
-    ``HMG_COMM=host-rehearsal`` the ranks exchange through files in /dev/shm instead (device -> host ->
-    file -> host -> device, blocking), which exercises everything else of the multi-rank path - slab
-    bounds, the gather landing every slab in place, barriers, the max-over-ranks timing, rank 0's
-    report.  Never the default, never a fallback: it is selected by name, it labels itself in the bench
-    line, and its timings mean nothing.  Same interface as RcclComm minus ``gather_rows_async``
-    (ShardedSpectra then takes its event-ordered ``allgather_rows`` branch)."""
-
-    def __init__(self, ctx, rank, world, tag, directory=None):
-        self.ctx, self.rank, self.world = ctx, rank, world
-        self._dir = directory or os.environ.get("HMG_REHEARSAL_DIR", "/dev/shm")
-        self._base = os.path.join(self._dir, f"hmg_reh_{tag}_w{world}_pp{os.getppid()}")
-        self._seq = 0
-
-    # -- pure-host core (CPU-testable): every rank contributes one array, every rank gets all of them
-    def exchange(self, arr):
-        self._seq += 1
-        mine = f"{self._base}_s{self._seq}_r{self.rank}.npy"
-        tmp = mine + ".tmp"
-        with open(tmp, "wb") as f:
-            np.save(f, np.ascontiguousarray(arr, dtype=np.float64))
-        os.replace(tmp, mine)
-        deadline = time.time() + float(os.environ.get("HMG_RDZV_TIMEOUT", "600"))
-        parts = []
-        for r in range(self.world):
-            path = f"{self._base}_s{self._seq}_r{r}.npy"
-            while not os.path.exists(path):
-                if time.time() > deadline:
-                    raise TimeoutError(f"rank {r} never wrote {path}")
-                time.sleep(0.0005)
-            parts.append(np.load(path))
-        # Having read round s, every rank had written its file of round s, i.e. had finished reading round
-        # s-1 (a rank writes round s only after that) - so my file of round s-1 has no reader left.  (Not
-        # round s itself: a slower rank may still be reading it.)
-        old = f"{self._base}_s{self._seq - 1}_r{self.rank}.npy"
-        if os.path.exists(old):
-            os.remove(old)
-        return parts
-
-    def allgather_rows(self, sends, recvs):
-        self.ctx.sync()                               # (blocking by design: the lanes are drained first)
-        flat = np.concatenate([s.numpy().reshape(-1) for s in sends])
-        parts = self.exchange(flat)
-        n = sends[0].size
-        for i, rcv in enumerate(recvs):
-            full = np.concatenate([p[i * n:(i + 1) * n] for p in parts])
-            nat.check(self.ctx.lib.hmg_memcpy_h2d(self.ctx.handle, rcv.ptr, full.ctypes.data, full.nbytes))
-
-    def allgather_host(self, values):
-        return np.stack(self.exchange(np.ascontiguousarray(values, dtype=np.float64)))
-
-    def barrier(self):
-        self.exchange(np.zeros(1))
-
-    def info(self):
-        return self.rank, self.world
-
-    def close(self):
-        # The file of the last round must outlive this rank: a slower rank may not have read it yet.  It is a
-        # few bytes; bench.py's launcher removes the leftovers of its ranks when they have all exited.
-        self.barrier()
-
-    @staticmethod
-    def cleanup(tag, world, parent_pid, directory=None):
-        import glob
-        d = directory or os.environ.get("HMG_REHEARSAL_DIR", "/dev/shm")
-        for f in glob.glob(os.path.join(d, f"hmg_reh_{tag}_w{world}_pp{parent_pid}_s*_r*.npy*")):
-            try:
-                os.remove(f)
-            except OSError:
-                pass
 
 
 class ShardedSpectra:
@@ -257,7 +206,7 @@ class ShardedSpectra:
         if hasattr(self.comm, "gather_rows_async"):
             self.comm.gather_rows_async(self.local, self.full, self._EV_SPECTRA, self._EV_GATHERED, self._COMM_LANE)
             return
-        ctx = self.model._ctx()            # communicators without the fused entry point (CPU rehearsal)
+        ctx = self.model._ctx()            # communicators without the fused entry point (tests/helpers)
         ctx.record(self._EV_SPECTRA)
         ctx.lane(self._COMM_LANE)
         ctx.wait(self._EV_SPECTRA)

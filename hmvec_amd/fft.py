@@ -34,6 +34,20 @@ def fft_integral(x, y, axis=-1):
     return ks, out.numpy().reshape(lead + (N // 2 + 1,))
 
 
+def uk_brute_force(r, rho, rvir, ks):
+    """The same transform by direct quadrature, u(k) = (4 pi / m) int_0^rvir dr r sin(kr) rho(r) / k with
+    m = 4 pi int_0^rvir dr r^2 rho (hmvec/fft.py:22-33; bin/tests.py:36 checks uk_fft against it).  r, rho:
+    (nr,) samples of the profile, ks: (nk,).  The (nk, nr) integrand and its trapezoid sums are evaluated on
+    the device (HMG_FN_BRUTE_INTEGRAND + hmg_trapz_rows)."""
+    from .functions import FN_BRUTE_INTEGRAND, fn2d
+    r, rho, ks = (np.asarray(a, dtype=np.float64) for a in (r, rho, ks))
+    keep = r < rvir
+    rs, rhos = r[keep], rho[keep]
+    mass = 4.0 * np.pi * float(trapz_lastaxis((rhos * rs ** 2.0)[None, :], rs)[0])
+    integrand = fn2d(FN_BRUTE_INTEGRAND, [rs[None, :], rhos[None, :], ks[:, None]])       # [k][r]
+    return trapz_lastaxis(integrand, rs) / mass
+
+
 def analytic_fft_integral(ks):
     """Closed form of fft_integral for y = exp(-x^2/2) (hmvec/fft.py:53); a check function."""
     ks = np.asarray(ks, dtype=np.float64)
@@ -87,4 +101,4 @@ def uk_fft(rhofunc, rvir, dr=0.001, rmax=100):
     return ks, uk
 
 
-__all__ = ["fft_integral", "analytic_fft_integral", "generic_profile_fft", "uk_fft"]
+__all__ = ["fft_integral", "analytic_fft_integral", "generic_profile_fft", "uk_fft", "uk_brute_force"]

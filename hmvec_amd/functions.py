@@ -24,7 +24,7 @@ from .params import battaglia_defaults, default_params
 (FN_TINKER_BIAS, FN_TINKER_FNU, FN_MHALO_STELLAR, FN_HOD_NC, FN_HOD_NS, FN_HOD_MFUNC, FN_HOD_NSNSM1,
  FN_HOD_NCNS, FN_FCON, FN_RHO_NFW, FN_R_FROM_M, FN_DUFFY, FN_BATT_FIT, FN_RHO_GAS_X, FN_RHO_GAS_R,
  FN_PE_X, FN_PE_R, FN_NGAL_INTEGRAND, FN_A2Z, FN_MDELTA, FN_BG_INTEGRAND, FN_ST_FSIGMA, FN_TINKER_FSIGMA, FN_WKR,
- FN_LINCOMB3, FN_MHALO_STELLAR_CORE) = range(26)
+ FN_LINCOMB3, FN_MHALO_STELLAR_CORE, FN_BRUTE_INTEGRAND) = range(27)
 
 _ctx_override = None
 

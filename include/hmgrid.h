@@ -443,7 +443,8 @@ int hmg_limber(hmg_ctx* ctx, int nells, const double* d_ells, int nz, int nk, co
                                     (total_matter_power_spectrum etc.)                 cosmology.py:599-658 */
 #define HMG_FN_MHALO_STELLAR_CORE 25 /* in log10mstellar, a; par Mstar00, Mstara, M1, M1a, beta0, beta_a, gamma0,
                                        gamma_a, delta0, delta_a                         hmvec.py:648-657 */
-#define HMG_FN_COUNT         26
+#define HMG_FN_BRUTE_INTEGRAND 26 /* in r, rho, k -> 4 pi r sin(r k) rho / k  (uk_brute_force)           fft.py:22-33 */
+#define HMG_FN_COUNT         27
 #define HMG_FN_MAXIN   6
 #define HMG_FN_MAXPAR 16
 int hmg_fn2d(hmg_ctx* ctx, int op, int rows, int cols, int nin, const double* const* h_d_in,

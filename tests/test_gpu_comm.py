@@ -1,6 +1,7 @@
-"""RCCL plumbing inside libhmgrid on one GPU: a 1-rank communicator exercises the same entry
-points the multi-GPU path uses (unique id -> file rendezvous -> ncclCommInitRank -> grouped
-all-gather -> all-reduce barrier).  The >1-rank logic is rehearsed on CPU in test_shard_gloo.py."""
+"""RCCL plumbing inside libhmgrid: on one GPU a 1-rank communicator exercises the same entry points the
+multi-GPU path uses (unique id -> file rendezvous -> ncclCommInitRank -> grouped all-gather -> all-reduce
+barrier) and two processes rehearse the slab flow over a file transport; where two devices are visible,
+two ranks run the real thing over RCCL.  The >1-rank logic is also rehearsed on CPU in test_shard_gloo.py."""
 import os
 
 import numpy as np
@@ -70,21 +71,18 @@ def test_gather_overlaps_on_its_own_lane_and_stays_ordered(tmp_path, monkeypatch
     ctx.close()
 
 
-def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path):
-    """The N > 1 data path minus RCCL itself (which refuses two ranks on one device): two processes, each
-    with the model of its z-slab, exchange through the file transport of HostRehearsalComm; what the
-    gather leaves in EVERY rank's full-grid buffers is, bit for bit, what one process computes on the
-    full redshift grid - slabs land in place and a slab reproduces its rows of the full grid exactly."""
-    import subprocess
-    import sys
+def _device_count():
+    import ctypes
+    n = ctypes.c_int(0)
+    try:
+        rc = ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
+    except OSError:
+        return 0
+    return n.value if rc == 0 else 0
+
+
+def _full_grid_reference():
     import hmvec_amd as hm
-    here = os.path.dirname(os.path.abspath(__file__))
-    worker = os.path.join(here, "helpers", "rehearsal_rank.py")
-    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"t{os.getpid()}", str(tmp_path), outs[r]])
-             for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=300) == 0
     zs = np.linspace(0.1, 2.6, 8)
     ms = np.geomspace(2e10, 1e16, 96)
     ks = np.geomspace(1e-3, 50, 384)
@@ -94,7 +92,54 @@ def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path):
     pairs = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("g", "electron"), ("nfw", "electron")]
     blk = h.spectra_block(pairs)          # the same batched mass-integral launch the ranks use
     blk.compute()
-    ref = {p: (a.copy(), b.copy()) for p, (a, b) in blk.fetch().items()}
+    return pairs, {p: (a.copy(), b.copy()) for p, (a, b) in blk.fetch().items()}
+
+
+def test_two_rank_rccl_gather_reproduces_the_full_grid(tmp_path):
+    """Config 4 in small: two ranks on two devices, z-slabs joined by the product's grouped RCCL all-gather
+    over xGMI; every rank's gathered buffers equal the one-process full grid bit for bit.  Needs two visible
+    devices (the development boxes have one: skipped there, runs wherever the hardware is)."""
+    import subprocess
+    import sys
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs")
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "helpers", "rehearsal_rank.py")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HMG_RDZV_TIMEOUT="120")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"rccl{os.getpid()}", str(tmp_path), outs[r], "rccl"],
+                              env=env) for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    pairs, ref = _full_grid_reference()
+    for r in range(2):
+        got = np.load(outs[r])
+        assert len(got.files) == 2 * len(pairs)
+        for key in got.files:
+            a, b, i = key.split("|")
+            assert np.array_equal(got[key], ref[(a, b)][int(i)]), (r, key)
+
+
+def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path):
+    """The N > 1 data path minus RCCL itself (which refuses two ranks on one device): two processes, each
+    with the model of its z-slab, exchange through the file transport of tests/helpers/rehearsal_comm.py; what the
+    gather leaves in EVERY rank's full-grid buffers is, bit for bit, what one process computes on the
+    full redshift grid - slabs land in place and a slab reproduces its rows of the full grid exactly."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "helpers", "rehearsal_rank.py")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"t{os.getpid()}", str(tmp_path), outs[r]])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    pairs, ref = _full_grid_reference()
     for r in range(2):
         got = np.load(outs[r])
         assert len(got.files) == 2 * len(pairs)

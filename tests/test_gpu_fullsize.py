@@ -202,3 +202,33 @@ def test_captured_step_replays_identically():
     again = blk.fetch()
     assert np.array_equal(again[PAIRS[2]][1], eager[PAIRS[2]][1])
     ctx.call("hmg_graph_destroy", gid)
+
+
+def test_no_block_changes_hands_inside_a_capture():
+    """The allocator recycles blocks by size.  Inside a capture that would bake a recycled address into the
+    graph while the block goes back to the list when its owner dies: EVERY allocation is refused there, also
+    one the free list could serve, and a block freed during a capture stays out of the list as long as the
+    graph that may use it exists."""
+    from hmvec_amd import _native as nat
+    ctx = nat.Context(0)
+    a = ctx.empty((1234,))
+    ptr_a = a.ptr
+    a.free()                                    # a same-size block now sits in the free list
+    keep = ctx.empty((777,))
+    ptr_k = keep.ptr
+
+    def body():
+        with pytest.raises(nat.NativeError, match="captured step"):
+            ctx.empty((1234,))                  # would have been served from the list
+        keep.free()                             # deferred: not dropped, not recycled yet
+
+    gid = ctx.capture(body)
+    b = ctx.empty((1234,))
+    assert b.ptr == ptr_a                       # outside the capture the list serves it again
+    c = ctx.empty((777,))
+    assert c.ptr != ptr_k                       # the block freed during the capture is still pinned to the graph
+    ctx.call("hmg_graph_destroy", gid)
+    c.free()
+    d, e = ctx.empty((777,)), ctx.empty((777,))
+    assert ptr_k in (d.ptr, e.ptr)              # ... and back in circulation once the graph is gone
+    ctx.close()

@@ -251,3 +251,11 @@ def test_cosmology_layer_names():
     with pytest.raises(NameError):
         h.C_gy(ells, zs, ks, Pge, 0.8, zmin=0.7, zmax=0.9)
     assert h.P_mm_linear(zs, ks) is None
+
+
+def test_uk_brute_force_against_the_reference():
+    """fft.uk_brute_force (hmvec/fft.py:22-33; bin/tests.py:36): direct quadrature of the profile transform."""
+    from hmvec_amd import fft as hfft
+    g = load_golden("extra_pins")
+    got = hfft.uk_brute_force(g["ub_r"], g["ub_rho"], 1.5, g["ub_k"])
+    assert rel_err(got, g["ub_u"]) < 1e-12

@@ -3,25 +3,49 @@ linear power spectrum comes from a Boltzmann-code provider instead of the closed
 spectrum (hmvec/cosmology.py:245-269,353-382,772-786).  CAMB itself cannot be installed in this
 image, so the provider is `TabulatedBackground`: a P(k,z) TABLE (what one would save from a CAMB
 run) whose z and k dependence does not factorise - the case the (z x k') . (k' x m) sigma^2
-contraction must handle in general.  The GPU path is compared with the oracle fed the SAME
-sPzk / Pzk arrays; what CAMB would have put in the table stays an unpinned input."""
+contraction must handle in general.  The GPU path is compared with the UNMODIFIED reference
+run on the same table (fixture case_e) and with the oracle fed the same sPzk / Pzk arrays; what CAMB itself
+would have put in the table stays an unpinned input."""
 import numpy as np
 import pytest
 
-from conftest import merged_params, power_close, rel_err
+import os
+import sys
+
+from conftest import load_golden, merged_params, power_close, rel_err
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+import pk_table  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
 
 def table(p):
-    zt = np.linspace(0.0, 3.2, 17)
-    kt = np.geomspace(5e-5, 3000.0, 600)
-    x = kt / 0.02
-    shape = 2.0e4 * x ** p["ns"] / (1.0 + x ** 2.9) ** 1.05 * (1.0 + 0.04 * np.sin(14.0 * np.log(kt)) * np.exp(-(kt / 0.3)))
-    growth = np.exp(-0.75 * zt) / (1.0 + 0.1 * zt)
-    # scale-dependent growth (as massive neutrinos give): P(k,z) is NOT D(z)^2 P0(k)
-    nonsep = 1.0 + 0.25 * np.tanh(zt[:, None] - 1.0) * np.log10(1.0 + kt[None, :] / 0.05) / 5.0
-    return zt, kt, shape[None, :] * growth[:, None] ** 2 * nonsep
+    return pk_table.table(p["ns"])
+
+
+@pytest.mark.parametrize("accuracy", ["medium", "high"])
+@pytest.mark.parametrize("mf,tag", [("sheth-torman", "st"), ("tinker", "tk")])
+def test_default_accuracies_against_the_reference_on_a_tabulated_spectrum(accuracy, mf, tag):
+    """The drop-in constructor with a Boltzmann-code provider, end to end against the UNMODIFIED reference
+    (tests/golden/case_e.npz: accuracy='medium'/'high' on the same table): the host seam feeds the device
+    path, sigma2 / n / b and three spectra come out as the reference's."""
+    import hmvec_amd as hm
+    g = load_golden("case_e")
+    p = merged_params()
+    h = hm.HaloModel(g["zs"], g["ks"], ms=g["ms"], mass_function=mf, accuracy=accuracy,
+                     background=hm.TabulatedBackground(p, *table(p)))
+    pre = f"{accuracy}_{tag}_"
+    assert rel_err(h.sPzk, g[f"{accuracy}_sPzk"]) < 1e-13 and rel_err(h.Pzk, g[f"{accuracy}_Pzk"]) < 1e-13
+    assert rel_err(h.sigma2, g[pre + "sigma2"]) < 1e-12
+    assert rel_err(h.bh, g[pre + "bh"]) < 1e-12
+    assert np.allclose(h.nzm, g[pre + "nzm"], rtol=1e-10, atol=1e-300)
+    meta = g["meta"]
+    h.add_battaglia_profile("electron", family="AGN", xmax=meta["xmax"], nxs=meta["nxs"])
+    h.add_hod("g", mthresh=10 ** 10.5 + g["zs"] * 0.0)
+    for a, b in (("nfw", "nfw"), ("electron", "electron"), ("g", "g")):
+        ok, w = power_close(h.get_power(a, b), g[pre + f"P_{a}_{b}"])
+        assert ok, (a, b, w)
 
 
 @pytest.mark.parametrize("accuracy", ["medium", "high"])

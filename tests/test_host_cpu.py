@@ -159,8 +159,48 @@ def test_bench_launcher_dry_run_and_failure_propagation():
         assert r.returncode != 0 and "rank exit codes" in r.stderr
 
 
+@pytest.mark.parametrize("failing", ["1", "0"])
+def test_bench_launcher_stops_everything_when_one_rank_dies(failing, capfd):
+    """A rank that dies before the communicator exists must not leave its peers waiting (in ncclCommInitRank,
+    at the rendezvous file) until the driver's time limit: the launcher polls ALL ranks, terminates the others
+    on the first non-zero exit, reports that rank's stderr and returns non-zero - in seconds."""
+    import argparse
+    import importlib.util
+    import sys
+    import time
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    helper = os.path.join(REPO, "tests", "helpers", "launcher_rank.py")
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=3, dry_run=False), [], cmd=[sys.executable, helper, failing, "120"])
+    took = time.monotonic() - t0
+    out, err = capfd.readouterr()
+    assert rc != 0 and took < 10.0, (rc, took)
+    assert f"rank {failing} exited with code 3" in err and "fails on purpose" in err
+
+
+def test_bench_launcher_deadline(monkeypatch, capfd):
+    """... and a launch in which nobody fails but nobody finishes either ends at its deadline."""
+    import argparse
+    import importlib.util
+    import sys
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("HMG_LAUNCH_DEADLINE", "1.5")
+    helper = os.path.join(REPO, "tests", "helpers", "launcher_rank.py")
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=2, dry_run=False), [], cmd=[sys.executable, helper, "none", "60"])
+    out, err = capfd.readouterr()
+    assert rc != 0 and "deadline" in err and "rank 0 started" in out
+
+
 def _rehearsal_rank(rank, world, tag, directory, q):
-    from hmvec_amd.dist import HostRehearsalComm
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    from rehearsal_comm import HostRehearsalComm
     c = HostRehearsalComm(None, rank, world, tag, directory=directory)
     got = c.exchange(np.arange(4.0) + 10.0 * rank)
     tim = c.allgather_host([1.5 + rank])
@@ -169,7 +209,7 @@ def _rehearsal_rank(rank, world, tag, directory, q):
 
 
 def test_host_rehearsal_comm_exchanges_between_processes(tmp_path):
-    """The file transport that rehearses bench.py --gpus N on a one-GPU box (HMG_COMM=host-rehearsal):
+    """The file transport that rehearses the N-rank flow on a one-GPU box (tests/helpers/rehearsal_comm.py):
     three processes, every rank receives every rank's array in rank order, several rounds."""
     import multiprocessing as mp
     world = 3

@@ -51,7 +51,8 @@ def test_two_rank_zslab_gather_matches_full_grid(tmp_path):
 
 def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
     """The 128-byte RCCL id travels from rank 0 to the other ranks through a file named after
-    the launch (MASTER_PORT, run id, world size, launcher pid); stale files are ignored."""
+    the launch (MASTER_PORT, run id, world size, launcher pid) that carries the launch nonce in front of the id;
+    a file with another nonce is ignored, whatever its age."""
     import ctypes
     import threading
     import time
@@ -71,11 +72,12 @@ def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
 
     tag = "29500_none"
     path = dist.rendezvous_path(tag, 2)
-    # a leftover from a crashed launch long ago must not be picked up
+    # a leftover of a crashed earlier launch with the SAME name (same port, same run id, a recycled launcher
+    # PID) must not be picked up, however fresh it looks: it carries another launch's nonce
+    other = bytearray(dist.launch_nonce(tag, 2))
+    other[-1] ^= 0x55
     with open(path, "wb") as f:
-        f.write(b"\xff" * nat.COMM_ID_BYTES)
-    old = time.time() - 3600
-    os.utime(path, (old, old))
+        f.write(bytes(other) + b"\xff" * nat.COMM_ID_BYTES)
     got = {}
 
     def reader():

@@ -64,8 +64,20 @@ def install_standin_camb():
                                   omk=k.get("omk", 0.0), w0=k.get("w", -1.0),
                                   wa=k.get("wa", 0.0), YHe=p.YHe)
 
+    def get_matter_power_interpolator(pars, nonlinear=False, hubble_units=True, k_hunit=True, kmax=None,
+                                      var1=None, var2=None, zmax=None, **kw):
+        """What hmvec/cosmology.py:783-786 asks CAMB for with accuracy='medium'/'high': an object with
+        .P(z, k, grid=True) in Mpc units.  Served from the table of tests/helpers/pk_table.py through this
+        repo's TabulatedPowerInterpolator (a spline of ln P in (z, ln k), as CAMB's own interpolator is)."""
+        assert not nonlinear and hubble_units is False and k_hunit is False and var1 == var2 == "delta_tot"
+        sys.path.insert(0, os.path.join(REPO, "tests", "helpers"))
+        from pk_table import table
+        from hmvec_amd.background import TabulatedPowerInterpolator
+        return TabulatedPowerInterpolator(*table(pars.kw["ns"]))
+
     camb.set_params = set_params
     camb.get_background = get_background
+    camb.get_matter_power_interpolator = get_matter_power_interpolator
     camb.model = model
     sys.modules["camb"] = camb
     sys.modules["camb.model"] = model
@@ -362,6 +374,54 @@ def run_function_pins(hm):
     return out
 
 
+def run_case_e(hm):
+    """Row N3: the UNMODIFIED reference with accuracy='medium' and 'high' (hmvec/hmvec.py:96-102,
+    hmvec/cosmology.py:255-260,353-389,772-786) on the tabulated P(k,z) the stand-in camb serves - the host
+    seam (P_lin, P_lin_slow, _get_matter_power) and everything downstream of it."""
+    zs = np.array([0.05, 0.6, 1.4, 2.2, 3.0])
+    ms = np.geomspace(1e10, 1e16, 36)
+    ks = np.geomspace(1e-4, 80.0, 45)
+    out = dict(zs=zs, ms=ms, ks=ks)
+    for acc in ("medium", "high"):
+        for mf, tag in (("sheth-torman", "st"), ("tinker", "tk")):
+            h = hm.HaloModel(zs, ks, ms=ms, mass_function=mf, accuracy=acc)
+            pre = f"{acc}_{tag}_"
+            if "in_h" not in out:
+                for k, v in cosmo_inputs(h, zs).items():
+                    if k not in ("Pzk", "sPzk"):
+                        out["in_" + k] = np.asarray(v)
+            if tag == "st":        # the spectra the path consumes do not depend on the mass function
+                out[f"{acc}_Pzk"], out[f"{acc}_sPzk"] = h.Pzk, h.sPzk
+            out[pre + "sigma2"], out[pre + "nzm"], out[pre + "bh"] = h.sigma2, h.nzm, h.bh
+            h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=400)
+            h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+            for a, b in (("nfw", "nfw"), ("electron", "electron"), ("g", "g")):
+                out[pre + f"P_{a}_{b}"] = h.get_power(a, b)
+    out["meta_json"] = np.array(json.dumps(dict(nxs=400, xmax=20, table="tests/helpers/pk_table.py")))
+    return out
+
+
+def run_extra_pins(hm):
+    """Helpers off the grid path that the reference exports and its own scripts use: Cosmology.sigma_crit
+    (hmvec/hmvec.py:595), Cosmology.bias_fnl (examples/fnl.py) and fft.uk_brute_force (bin/tests.py:36)."""
+    import hmvec.fft as rfft
+    out = {}
+    zs = np.linspace(0.1, 1.5, 6)
+    ks = np.geomspace(1e-3, 5.0, 40)
+    h = hm.HaloModel(zs, ks, ms=np.geomspace(1e11, 1e15, 8), accuracy="low", skip_nfw=True)
+    out["zs"], out["ks"] = zs, ks
+    out["sigma_crit"] = h.sigma_crit(zs, 2.0)
+    for z in (0.0, 0.8):
+        out[f"bias_fnl_z{z}"] = h.bias_fnl(1.8, 25.0, z, ks)
+    out["bias_fnl_deltac"] = h.bias_fnl(2.4, -10.0, 0.5, ks, deltac=1.686)
+    r = np.arange(0.01, 4.0, 0.01)
+    rho = 1.0 / (r / 0.2) / (1.0 + r / 0.2) ** 2
+    kb = np.geomspace(0.05, 40.0, 25)
+    out["ub_r"], out["ub_rho"], out["ub_k"] = r, rho, kb
+    out["ub_u"] = rfft.uk_brute_force(r, rho, 1.5, kb)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -420,6 +480,11 @@ def main():
                                 np.geomspace(2e10, 1e17, 26), nxs=400, pres=True, second_tracers=True,
                                 params=dict(sigma2_numks=3000),
                                 limber=dict(ells=np.linspace(100, 6000, 10), lzs=2.5, gzs=0.8)))
+    # E: accuracy='medium' / 'high' on a tabulated, non-separable P(k,z) (row N3's host seam)
+    if want("case_e"):
+        save("case_e", run_case_e(hm))
+    if want("extra_pins"):
+        save("extra_pins", run_extra_pins(hm))
     if not args.skip_readme:
         if want("readme_c1"):
             save("readme_c1", run_readme_anchor(hm))
