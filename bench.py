@@ -39,7 +39,7 @@ PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"),
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_CYCLES = 4      # a wave64 fp64 VALU instruction occupies its SIMD-32 for 4 cycles
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-PROFILE_DIR = os.path.join(REPO, "profiles", "r02")
+PROFILE_DIR = os.path.join(REPO, "profiles", "r03")
 BRACKET_EVERY = 4         # kernel-level HIP events ride on every 4th timed step
 
 
@@ -222,7 +222,7 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
                      "threadpools": pools})
     if allcore and avail > 1:
         nproc = 1
-        for cand in (16, 8, 4, 2):          # a divisor of nz within the box's CPU share for one GPU (16)
+        for cand in (zs.size, 16, 8, 4, 2):   # a divisor of nz the box can run at once: one redshift per process (32) where it can
             if cand <= avail and zs.size % cand == 0:
                 nproc = cand
                 break
@@ -234,7 +234,7 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
         wall = time.perf_counter() - t0
         slowest = max(bests)
         rec["all_cores"] = dict(value=len(PAIRS) * zs.size * ms.size * ks.size / slowest, unit="grid-points/s",
-                                cores=nproc, seconds=slowest,
+                                cores=nproc, pool_size=nproc, hardware_threads=avail, seconds=slowest,
                                 sample=f"all {zs.size} redshifts as {nproc} z-slabs of {per} over a process pool "
                                        f"(one single-threaded oracle per core; slowest slab's best of 2; pool wall {wall:.1f} s)")
     return rec, sel, out
@@ -437,10 +437,24 @@ def main():
         return
 
     # ---- bytes: the implementation's own model and, for the default configuration,
-    # the PMC counters of profiles/r02 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+    # the PMC counters of profiles/r03 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
     default_cfg = (args.nz, args.nm, args.nk, args.nxs) == (32, 512, 4096, 5000) and world == 1 and not args.per_pair
-    pmc = load_profile("pmc_traffic.json") if default_cfg else None
-    sq = load_profile("sq_issue_counters.json") if default_cfg else None
+    sha = nat.kernel_source_sha16()
+    stale = []
+
+    def stored(name):
+        """A stored counter profile counts only for the build it was measured on."""
+        d = load_profile(name) if default_cfg else None
+        if d is not None and d.get("source_sha16") != sha:
+            stale.append(f"{name}: measured on kernel sources {d.get('source_sha16')}, this build is {sha}")
+            return None
+        return d
+
+    pmc = stored("pmc_traffic.json")
+    sq = stored("sq_issue_counters.json")
+    grouped = h._groups
+    KNAME = {"power": "power_batch_kernel", "nfw": "rows_group_kernel" if grouped else "nfw_kernel",
+             "fft": "profile_group_kernel" if grouped else "profile_fused_kernel"}
 
     def pmc_bytes(sub):
         if not pmc:
@@ -476,7 +490,7 @@ def main():
         ms_ = kms[key]
         moved = pmc_bytes(sub) or model[key]
         e = {"bound": bound, "ms": ms_, "bytes_moved": moved,
-             "bytes_source": "pmc (profiles/r02/pmc_traffic.json)" if pmc_bytes(sub) else "model (DESIGN.md section 4)",
+             "bytes_source": "pmc (profiles/r03/pmc_traffic.json)" if pmc_bytes(sub) else "model (DESIGN.md section 4)",
              "bytes_model": model[key], "hbm_GBps": moved / (ms_ * 1e-3) / 1e9 if ms_ else None,
              "hbm_frac": moved / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ else None,
              "survey_alg_bytes": alg[key], "note": note}
@@ -487,16 +501,33 @@ def main():
         return e
 
     kernels = {
-        "power_batch_kernel": kernel_entry("power", "power_batch_kernel", "hbm",
+        "power_batch_kernel": kernel_entry("power", KNAME["power"], "hbm",
                                            "fused 1h+2h mass integrals of all 6 spectra, 1 launch/step; the constant "
                                            "left-fill prefix of the Battaglia tensor is substituted, not read"),
-        "nfw_kernel": kernel_entry("nfw", "nfw_kernel", "fp64-valu",
-                                   "series / Si-Ci evaluation per point, one 8-B store per point"),
-        "profile_fused_kernel": kernel_entry("fft", "profile_fused_kernel", "fp64-valu + LDS",
+        "nfw_kernel": kernel_entry("nfw", KNAME["nfw"], "fp64-valu",
+                                   "series / Si-Ci evaluation per point, one 8-B store per point"
+                                   + ("; launched as hmg::rows_group_kernel: n(z,m), b(z,m) tiles | Battaglia row "
+                                      "parameters | NFW rows in one grid" if grouped else "")),
+        "profile_fused_kernel": kernel_entry("fft", KNAME["fft"], "fp64-valu + LDS",
                                              "integrand + in-LDS packed-real FFT + k-interpolation per (z,m) row; "
-                                             "HBM traffic = the output row"),
+                                             "HBM traffic = the output row"
+                                             + ("; launched as hmg::profile_group_kernel: per-z chain (HOD sums -> "
+                                                "coefficient rows) | profile rows in one grid" if grouped else "")),
     }
+    for key, name in (("power_batch_kernel", "power"), ("nfw_kernel", "nfw"), ("profile_fused_kernel", "fft")):
+        kernels[key]["launched_as"] = "hmg::" + KNAME[name]
     pw = kernels["power_batch_kernel"]
+    # the kernel the step spends most of its time in is VALU/LDS-bound, not HBM-bound: its own roofline block
+    dom_key = max(kernels, key=lambda k: kernels[k]["ms"] or 0.0)
+    dom = kernels[dom_key]
+    roofline_time_dominant = {
+        "kernel": dom["launched_as"], "share_of_step": (dom["ms"] or 0.0) / (dt_max / K * 1e3),
+        "bound": dom["bound"], "ms_per_launch": dom["ms"],
+        "valu_insts_per_wave": dom.get("valu_insts_per_wave"), "valu_issue_bound_ms": dom.get("valu_issue_bound_ms"),
+        "valu_issue_frac": dom.get("valu_issue_frac"),
+        "hbm_GBps": dom["hbm_GBps"], "hbm_frac": dom["hbm_frac"],
+        "note": "valu_issue_frac = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz / measured time (a wave64 fp64 VALU "
+                "instruction holds its SIMD-32 for 4 cycles); null when no counter profile of this build is stored"}
     step_bytes = None
     if pmc:
         step_bytes = float(sum(r["hbm_bytes_per_launch_corrected"] * r.get("launches_per_step", 1)
@@ -571,7 +602,7 @@ def main():
         "roofline": {"kernel": "hmg::power_batch_kernel" if not args.per_pair else "hmg::power_kernel x6 (per-pair path)",
                      "bound": "hbm", "achieved": pw["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": pw["hbm_frac"], "traffic": pmc_bytes("power_batch_kernel"),
-                     "traffic_source": ("stored profile profiles/r02/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                     "traffic_source": ("stored profile profiles/r03/pmc_traffic.json of this build: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                         "separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch "
                                         "(gfx950 FETCH_SIZE correction)") if pmc else None,
                      "bytes_moved": pw["bytes_moved"], "bytes_source": pw["bytes_source"], "bytes_model": pw["bytes_model"],
@@ -582,7 +613,12 @@ def main():
                              "configuration is stored, else the launch's own skip rule evaluated on the hint array); "
                              "alg_equiv_GBps prices the SURVEY 8d algorithmic bytes, of which the hinted constant prefix "
                              "is never read"},
+        "roofline_time_dominant": roofline_time_dominant,
         "kernels": kernels,
+        "launches_per_step": 4 if grouped else 8,
+        "launch_grouping": ("front (sigma^2 contraction | halo stage | HOD occupations), rows group, profile group, "
+                            "mass integrals" if grouped else "one launch per stage (HMG_NO_GROUPS=1)"),
+        "kernel_source_sha16": sha, "stale_profiles_ignored": stale or None,
         "step_hbm_bytes": step_bytes,
         "step_hbm_frac": step_bytes / (dt_max / K) / 1e9 / HBM_PEAK_GBS,
         "survey_alg_bytes_per_step": float(sum(alg.values()) + (sum([1, 1, 1, 2, 1, 2]) - 2) * tens_bytes),

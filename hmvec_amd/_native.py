@@ -166,6 +166,7 @@ SIGNATURES = {
                        C.POINTER(NfwPart)],
     "hmg_group_profile": [_P, _I, _I, _I, C.POINTER(ProfileFftPart), C.POINTER(HodPart), C.POINTER(PowerBatchDesc)],
     "hmg_power_batch_run": [_P, _I, _I, _I, C.POINTER(PowerBatchDesc), _I],
+    "hmg_add": [_P, _Z, _P, _P, _P],
     "hmg_limber": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "hmg_fn2d": [_P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_D), _I, _P],
     "hmg_mstellar_halo": [_P, _I, _I, _P, _P, _P],
@@ -183,6 +184,19 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def kernel_source_sha16():
+    """First 16 hex digits of the SHA-256 over the kernel sources and their build recipe: what a stored
+    profile (profiles/rNN/*.json) records and bench.py compares, so that counters measured on one build are
+    never quoted for another."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for name in ("hmgrid.hip", "sici.hpp", "ldsfft.hpp", "fastmath.hpp", "Makefile"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def load():

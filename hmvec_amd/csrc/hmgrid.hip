@@ -2492,6 +2492,13 @@ __global__ __launch_bounds__(1024) void mstellar_halo_kernel(int nm, const doubl
     for (int m = threadIdx.x; m < nm; m += blockDim.x) out[(size_t)z * nm + m] = shmr_inverse(mh, lmh[m]);
 }
 
+// out = a + b (get_power = P_1h + P_2h on the device: one array crosses PCIe instead of two)
+__global__ void add2_kernel(size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                            double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
 // np.trapz(y, x, axis=-1): sum_i (x[i+1]-x[i]) * (y[i+1]+y[i]) / 2, one block per row.
 __global__ __launch_bounds__(256) void trapz_rows_kernel(int cols, const double* __restrict__ y,
                                                          const double* __restrict__ x,
@@ -3919,6 +3926,14 @@ int hmg_mstellar_halo(hmg_ctx* c, int nz, int nm, const double* zs, const double
     REQUIRE(c && zs && lmh && out, "NULL argument");
     REQUIRE(nz > 0 && nm > 0, "empty grid");
     hipLaunchKernelGGL(mstellar_halo_kernel, dim3(nz), dim3(1024), 0, c->stream, nm, zs, lmh, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hmg_add(hmg_ctx* c, size_t n, const double* a, const double* b, double* out) {
+    REQUIRE(c && a && b && out, "NULL argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(add2_kernel, grid1d(n, 256), dim3(256), 0, c->stream, n, a, b, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -928,7 +928,7 @@ class HaloModel(Cosmology):
                     seen.append(nm_)
         self._tsz_notice(*seen)
         o1, o2 = self.power_device_batch(pairs)
-        return {tuple(p): a.numpy() + b.numpy() for p, a, b in zip(pairs, o1, o2)}
+        return {tuple(p): self._sum_on_device(a, b) for p, a, b in zip(pairs, o1, o2)}
 
     def _tsz_notice(self, *names):
         """The reference prints this once per pressure tracer in every 2-halo evaluation
@@ -1012,7 +1012,14 @@ class HaloModel(Cosmology):
             d1, d2 = self.power_device(name, name2, b1, b2)
         if verbose:
             self._print_consistency(name, name2)
-        return d1.numpy() + d2.numpy()
+        return self._sum_on_device(d1, d2)
+
+    def _sum_on_device(self, d1, d2):
+        """P_1h + P_2h added on the device: one array crosses PCIe (hmvec/hmvec.py:500-502)."""
+        ctx = self._ctx()
+        out = ctx.empty(d1.shape)
+        ctx.call("hmg_add", d1.size, d1.ptr, d2.ptr, out.ptr)
+        return out.numpy()
 
     def get_power_1halo(self, name="nfw", name2=None):
         """hmvec/hmvec.py:504-526."""

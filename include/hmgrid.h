@@ -393,6 +393,10 @@ int hmg_group_profile(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_profile_ff
 #define HMG_PB_PREPARED 1
 int hmg_power_batch_run(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_power_batch_desc* h_desc, int flags);
 
+/* d_out[i] = d_a[i] + d_b[i]: HaloModel.get_power = get_power_1halo + get_power_2halo (hmvec/hmvec.py:500-502)
+ * summed on the device, so that one (nz,nk) array crosses PCIe instead of two.                          */
+int hmg_add(hmg_ctx* ctx, size_t n, const double* d_a, const double* d_b, double* d_out);
+
 /* ---- N1: Limber projection ------------------------------------------------------------------
  * Replaces limber_integral (hmvec/cosmology.py:867-904): for every multipole,
  *   C_ell = sum_g wz[g] * pref[g] * P(z = gzs[g], k = (ell + 1/2)/chis[g]),

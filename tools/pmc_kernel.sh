@@ -19,7 +19,9 @@ for f in glob.glob(f"{out}/g*/p_counter_collection.csv"):
         k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 import json
-json.dump({"source": "rocprofv3 --pmc <SQ group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph "
+sys.path.insert(0, ".")
+from hmvec_amd._native import kernel_source_sha16
+json.dump({"source_sha16": kernel_source_sha16(), "source": "rocprofv3 --pmc <SQ group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph "
                      "(tools/pmc_kernel.sh); per-launch averages",
            "kernels": {k: {c: tot[k][c] / n[k][c] for c in sorted(tot[k])} for k in sorted(tot)}},
           open(f"{out}/sq_issue_counters.json", "w"), indent=1)

@@ -35,7 +35,10 @@ for r in csv.DictReader(open(f"{out}/pmc_fetch_counter_collection.csv")):
 steps = max([v for k, v in cnt.items() if "power_batch_kernel" in k] + [1])     # one mass-integral launch per step
 f = per_kernel(f"{out}/pmc_fetch_counter_collection.csv", "FETCH_SIZE")
 w = per_kernel(f"{out}/pmc_write_counter_collection.csv", "WRITE_SIZE")
-res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
+sys.path.insert(0, ".")
+from hmvec_amd._native import kernel_source_sha16
+res = {"source_sha16": kernel_source_sha16(),
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
                  "--no-cpu-baseline --no-limber --no-graph; Config 3, 1 GPU (tools/profile_round.sh)",
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
                      "MI355X_MICROARCH.md, HBM section)",
@@ -48,7 +51,7 @@ for k, v in res["kernels"].items():
 PY
 # SQ issue counters (five more passes), then install both summaries where bench.py reads them, so that the
 # bench line below is derived from the counters of THIS build on THIS box
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 bash tools/pmc_kernel.sh > $OUT/sq_issue_counters.txt
 cp gpurun_out/pmc_sq/sq_issue_counters.json $OUT/sq_issue_counters.json
 mkdir -p profiles/$ROUND
