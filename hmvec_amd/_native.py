@@ -161,7 +161,8 @@ SIGNATURES = {
                         _P, _P, _P, _P, _P, _P, _D, _D, C.POINTER(_P), C.POINTER(_P)],
     "hmg_power_2halo_terms": [_P, _I, _I, _I, C.POINTER(Tracer), C.POINTER(Tracer), _P, _P, _P, _P, _P, _D,
                               _P, _P, _P],
-    "hmg_sigma2_halo_front": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P, C.POINTER(HaloStageArgs), C.POINTER(HodPart)],
+    "hmg_sigma2_halo_front": [_P, _I, _I, _I, _P, _P, _P, _P, _D, _P, C.POINTER(HaloStageArgs), C.POINTER(HodPart),
+                              C.POINTER(RowsPart)],
     "hmg_group_rows": [_P, _I, _I, _I, _I, C.POINTER(MassFnPart), C.POINTER(HodPart), C.POINTER(RowsPart),
                        C.POINTER(NfwPart)],
     "hmg_group_profile": [_P, _I, _I, _I, C.POINTER(ProfileFftPart), C.POINTER(HodPart), C.POINTER(PowerBatchDesc)],

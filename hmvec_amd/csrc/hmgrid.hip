@@ -503,7 +503,7 @@ constexpr int MF_TILE = 62;
 __device__ __forceinline__ void sigma2_massfn_tile(const SigmaMassFnArgs& A, int z, int tile, double* red, double* sig) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nm = A.nm, n = A.nz * nm, m0 = tile * MF_TILE;
-    {   // slot `lane` <-> mass m0 - 1 + lane (clamped to the row)
+    if (w < 4) {   // slot `lane` <-> mass m0 - 1 + lane (clamped to the row)
         const int m = min(max(m0 - 1 + lane, 0), nm - 1);
         red[w * 64 + lane] = sigma2_segment_sum(n, A.parts, A.partial, (size_t)z * nm + m, w);
     }
@@ -658,7 +658,8 @@ struct NfwArgs {
 __device__ __forceinline__ void nfw_rows(const SiciTable* __restrict__ T, const double* __restrict__ acoef, int ktile,
                                          int nm, int nk, const double* __restrict__ cs,
                                          const double* __restrict__ rss, const double* __restrict__ zs,
-                                         const double* __restrict__ ks, double* __restrict__ uk, int blk, int nthr) {
+                                         const double* __restrict__ ks, double* __restrict__ uk, int blk, int nthr,
+                                         int tid) {
     // one (z,m) row per workgroup, the whole k axis in one tile: measured against two rows per workgroup
     // (+4 %), half tiles (+40 %) and 128 threads per row (+-0): a workgroup's fixed cost is the latency of
     // its scalar loads (row constants, series coefficients), not instructions
@@ -676,7 +677,7 @@ __device__ __forceinline__ void nfw_rows(const SiciTable* __restrict__ T, const 
     const double ln_opc = a[NFW_NS2 + 0], inv_mc = a[NFW_NS2 + 1], inv_opc2 = a[NFW_NS2 + 2];
     const bool use_series = (a[0] != 0.0);
     double* __restrict__ dst = uk + (size_t)row * nk;
-    for (int k = k_lo + threadIdx.x; k < k_hi; k += nthr) {
+    for (int k = k_lo + tid; k < k_hi; k += nthr) {
         const double x = ks[k] * rs * z1;
         const double xc = opc * x;
         if (use_series && xc <= 4.0) {
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* 
                                                   const double* __restrict__ cs, const double* __restrict__ rss,
                                                   const double* __restrict__ zs, const double* __restrict__ ks,
                                                   double* __restrict__ uk) {
-    nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, blockIdx.x, blockDim.x);
+    nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, blockIdx.x, blockDim.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------- A8/X1: row parameters
@@ -857,7 +858,9 @@ struct HaloStageArgs {
     const double* rho2;
     double *m2, *r2 /* both or neither */;
 };
-__device__ __forceinline__ void halo_stage_point(const HaloStageArgs& H, int idx) {
+// (rv_out, m2_out, r2_out: the values just stored, for a caller that goes on to the Battaglia row parameters)
+__device__ __forceinline__ void halo_stage_point(const HaloStageArgs& H, int idx, double* rv_out = nullptr,
+                                                 double* m2_out = nullptr, double* r2_out = nullptr) {
     const int z = idx / H.nm, m = idx - z * H.nm;
     const double mm = H.ms[m];
     const double c = H.A * pow(H.h * mm / 2.0e12, H.alpha) * pow(1.0 + H.zs[z], H.beta);
@@ -865,10 +868,13 @@ __device__ __forceinline__ void halo_stage_point(const HaloStageArgs& H, int idx
     H.cs[idx] = c;
     H.rv[idx] = r;
     H.rs[idx] = r / c;
+    if (rv_out) *rv_out = r;
     if (H.m2) {
         const double M2 = mdelta_solve(mm, c, H.d1[z] / (H.delta2 * H.rho2[z]));
+        const double R2 = cbrt(3.0 * M2 / 4.0 / M_PI / H.delta2 / H.rho2[z]);
         H.m2[idx] = M2;
-        H.r2[idx] = cbrt(3.0 * M2 / 4.0 / M_PI / H.delta2 / H.rho2[z]);
+        H.r2[idx] = R2;
+        if (m2_out) { *m2_out = M2; *r2_out = R2; }
     }
     if (H.series) nfw_series_row(c, H.series + (size_t)idx * NFW_ROW);
 }
@@ -1272,6 +1278,8 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
     int nleft = 0;     // wave-uniform count of left-filled targets seen by this wavefront
     for (int i = threadIdx.x; i < A.nk; i += NT) {
+        // (requesting the next trip's wavenumber one trip ahead was measured: +-0, the other wavefronts of the
+        // workgroup already cover the load)
         const double k = A.ks[i];
         double val;
         const bool left = k < k_lo;
@@ -2115,6 +2123,14 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs
 // -> HOD -> coefficient rows of the batched mass integrals, one workgroup per redshift, each link optional.
 // Every role runs the device function of its stand-alone kernel, so grouped and separate launches give
 // the same bits (tests/test_gpu_groups.py).
+struct RowsArgs {
+    int n;            // nz*nm, 0: no such role in this launch
+    int kind, nm;
+    const double *m200, *r200, *rvir, *zs, *rhoc, *hz;
+    RowFit F;
+    double gamma, alpha_const, pref, post_pref;
+    RowOut O;
+};
 struct SigmaFrontArgs {
     int nz, nzp, nm, nq, gx, nseg;
     const double *PT, *kq, *wq, *R;
@@ -2123,7 +2139,7 @@ struct SigmaFrontArgs {
 };
 template <int ZB>
 __global__ __launch_bounds__(64, HMG_SIG_OCC) void front_group_kernel(SigmaFrontArgs G, HaloStageArgs H, int nhalo,
-                                                                     HodRowArgs O, int nocc) {
+                                                                     HodRowArgs O, int nocc, RowsArgs Rw) {
     int b = blockIdx.x;
     if (b < nocc) {               // HOD occupations: the longest dependent chain of the launch, so first in the grid
         const int idx = b * 64 + threadIdx.x;
@@ -2133,7 +2149,17 @@ __global__ __launch_bounds__(64, HMG_SIG_OCC) void front_group_kernel(SigmaFront
     b -= nocc;
     if (b < nhalo) {
         const int idx = b * 64 + threadIdx.x;
-        if (idx < H.nz * H.nm) halo_stage_point(H, idx);
+        if (idx < H.nz * H.nm) {
+            // the Battaglia row parameters need only what this thread has just computed (M_200c, R_200c, r_vir):
+            // the same thread goes on to them, from the same values the stand-alone launch would load
+            double rv, m2, r2;
+            halo_stage_point(H, idx, &rv, &m2, &r2);
+            if (Rw.n) {
+                const int z = idx / Rw.nm;
+                rowparams_body(Rw.kind, idx, m2, r2, rv, 1.0 + Rw.zs[z], Rw.rhoc[z], Rw.hz ? Rw.hz[z] : 1.0, Rw.F,
+                               Rw.gamma, Rw.alpha_const, Rw.pref, Rw.post_pref, Rw.O);
+            }
+        }
         return;
     }
     b -= nhalo;
@@ -2179,14 +2205,6 @@ __device__ __forceinline__ void chain_row(const ChainArgs& C, int z, double* lds
         for (int blk = threadIdx.x >> 6; blk < C.PA.nblk; blk += NT / 64) batch_prep_tile_compact(C.PA, z, blk);
 }
 
-struct RowsArgs {
-    int n;            // nz*nm, 0: no such role in this launch
-    int kind, nm;
-    const double *m200, *r200, *rvir, *zs, *rhoc, *hz;
-    RowFit F;
-    double gamma, alpha_const, pref, post_pref;
-    RowOut O;
-};
 __device__ __forceinline__ void rows_block(const RowsArgs& Rw, int b) {
     const int idx = b * 256 + threadIdx.x;
     if (idx < Rw.n) {
@@ -2233,7 +2251,7 @@ __global__ __launch_bounds__(256, HMG_ROWS_OCC) void rows_group_kernel(RowsGroup
         rows_block(G.Rw, b);
         return;
     }
-    nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, b - G.nrowblk, 256);
+    nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, b - G.nrowblk, 256, threadIdx.x);
 }
 
 template <int MAXB, int MAXP, int SPECM>
@@ -3726,6 +3744,23 @@ int hmg_power_batch(hmg_ctx* c, int nz, int nm, int nk, int ntr, const hmg_trace
 }
 
 // ---- grouped launches ---------------------------------------------------------------------------
+static int rows_setup(int nz, int nm, const hmg_rows_part* rows, RowsArgs* out) {
+    RowsArgs Rw{};
+    REQUIRE(rows->d_m200c && rows->d_r200c && rows->d_rvir && rows->d_zs && rows->d_rhocz && rows->d_amp && rows->d_xc &&
+                rows->d_alpha && rows->d_expo && rows->d_cmax && rows->d_rscale, "NULL argument in the rows part");
+    REQUIRE(rows->kind == HMG_PROF_BATTAGLIA_GAS || rows->kind == HMG_PROF_BATTAGLIA_PRES, "unknown profile kind");
+    REQUIRE(rows->kind != HMG_PROF_BATTAGLIA_PRES || (rows->d_hz && rows->d_post), "pressure needs d_hz and d_post");
+    Rw.n = nz * nm; Rw.kind = rows->kind; Rw.nm = nm;
+    Rw.m200 = rows->d_m200c; Rw.r200 = rows->d_r200c; Rw.rvir = rows->d_rvir; Rw.zs = rows->d_zs;
+    Rw.rhoc = rows->d_rhocz; Rw.hz = rows->d_hz;
+    for (int i = 0; i < 9; ++i) Rw.F.f[i] = rows->fit[i];
+    Rw.gamma = rows->gamma; Rw.alpha_const = rows->alpha_const; Rw.pref = rows->amp_prefactor;
+    Rw.post_pref = rows->post_prefactor;
+    Rw.O = RowOut{rows->d_amp, rows->d_xc, rows->d_alpha, rows->d_expo, rows->d_cmax, rows->d_rscale, rows->d_post};
+    *out = Rw;
+    return 0;
+}
+
 static int hod_args(int nm, const hmg_hod_part* hod, HodRowArgs* A) {
     const hmg_hod_params* p = hod->h_par;
     REQUIRE(p && hod->d_zs && hod->d_ms && hod->d_log10mstar_thresh && hod->d_Nc && hod->d_Ns && hod->d_NsNsm1 &&
@@ -3742,7 +3777,7 @@ static int hod_args(int nm, const hmg_hod_part* hod, HodRowArgs* A) {
 
 int hmg_sigma2_halo_front(hmg_ctx* c, int nz, int nm, int nq, const double* PT, const double* kq, const double* wq,
                           const double* R, double tswitch, const double* ms, const hmg_halo_stage_args* h,
-                          const hmg_hod_part* hod) {
+                          const hmg_hod_part* hod, const hmg_rows_part* rows) {
     REQUIRE(c && PT && kq && wq && R, "NULL argument");
     REQUIRE(nz > 0 && nm > 0 && nq > 0, "empty grid");
     HaloStageArgs H;
@@ -3754,6 +3789,12 @@ int hmg_sigma2_halo_front(hmg_ctx* c, int nz, int nm, int nq, const double* PT, 
         if (hod_args(nm, hod, &O)) return 1;
         nocc = (nz * nm + 63) / 64;
     }
+    RowsArgs Rw{};
+    if (rows) {
+        if (rows_setup(nz, nm, rows, &Rw)) return 1;
+        REQUIRE(h->d_m2 && rows->d_m200c == h->d_m2 && rows->d_r200c == h->d_r2 && rows->d_rvir == h->d_rvir,
+                "row parameters in the front launch take M_200c, R_200c, r_vir from the halo stage of the same call");
+    }
     const int nseg = (nq + SIG_SEG_LEN - 1) / SIG_SEG_LEN;
     const int ztile = sigma2_ztile(nz), nzp = sigma2_nzp(nz);
     if (ensure_scratch(c, 4, (size_t)nseg * nz * nm * 8)) return 1;
@@ -3764,9 +3805,9 @@ int hmg_sigma2_halo_front(hmg_ctx* c, int nz, int nm, int nq, const double* PT, 
     const SigmaFrontArgs G{nz, nzp, nm, nq, gx, nseg, PT, kq, wq, R, tswitch, (double*)c->scratch[4]};
     const dim3 grid((unsigned)(nsig + nhalo + nocc));
     if (ztile == 32)
-        hipLaunchKernelGGL(front_group_kernel<2>, grid, dim3(64), 0, c->stream, G, H, nhalo, O, nocc);
+        hipLaunchKernelGGL(front_group_kernel<2>, grid, dim3(64), 0, c->stream, G, H, nhalo, O, nocc, Rw);
     else
-        hipLaunchKernelGGL(front_group_kernel<1>, grid, dim3(64), 0, c->stream, G, H, nhalo, O, nocc);
+        hipLaunchKernelGGL(front_group_kernel<1>, grid, dim3(64), 0, c->stream, G, H, nhalo, O, nocc, Rw);
     HIP_TRY(hipGetLastError());
     c->sig_nz = nz; c->sig_nm = nm; c->sig_nq = nq;
     return 0;
@@ -3833,19 +3874,7 @@ int hmg_group_rows(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_massfn_
     SigmaMassFnArgs S;
     if (mf && massfn_setup(c, nz, nm, nq, mf, &S)) return 1;
     RowsArgs Rw{};
-    if (rows) {
-        REQUIRE(rows->d_m200c && rows->d_r200c && rows->d_rvir && rows->d_zs && rows->d_rhocz && rows->d_amp && rows->d_xc &&
-                    rows->d_alpha && rows->d_expo && rows->d_cmax && rows->d_rscale, "NULL argument in the rows part");
-        REQUIRE(rows->kind == HMG_PROF_BATTAGLIA_GAS || rows->kind == HMG_PROF_BATTAGLIA_PRES, "unknown profile kind");
-        REQUIRE(rows->kind != HMG_PROF_BATTAGLIA_PRES || (rows->d_hz && rows->d_post), "pressure needs d_hz and d_post");
-        Rw.n = nz * nm; Rw.kind = rows->kind; Rw.nm = nm;
-        Rw.m200 = rows->d_m200c; Rw.r200 = rows->d_r200c; Rw.rvir = rows->d_rvir; Rw.zs = rows->d_zs;
-        Rw.rhoc = rows->d_rhocz; Rw.hz = rows->d_hz;
-        for (int i = 0; i < 9; ++i) Rw.F.f[i] = rows->fit[i];
-        Rw.gamma = rows->gamma; Rw.alpha_const = rows->alpha_const; Rw.pref = rows->amp_prefactor;
-        Rw.post_pref = rows->post_prefactor;
-        Rw.O = RowOut{rows->d_amp, rows->d_xc, rows->d_alpha, rows->d_expo, rows->d_cmax, rows->d_rscale, rows->d_post};
-    }
+    if (rows && rows_setup(nz, nm, rows, &Rw)) return 1;
     NfwArgs N{};
     size_t nfw_blocks = 0;
     int stop = -1;

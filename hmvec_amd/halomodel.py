@@ -340,7 +340,10 @@ class HaloModel(Cosmology):
                 occ.stage, st["hod"].stage = nat.HOD_OCCUPATIONS, nat.HOD_SUMS
                 hod_sums = True  # ... and n_gal, b_g, which need the n, b of this pass, in the profile group's chain
             args = st.pop("front")
-            ctx.call_now("hmg_sigma2_halo_front", *args[:-1], C.byref(args[-1]), C.byref(occ) if occ is not None else None)
+            # ... and so do the Battaglia row parameters: the thread that solves for M_200c goes on to them
+            rows = st.pop("rows") if "rows" in st and "rows_alone" not in x else None
+            ctx.call_now("hmg_sigma2_halo_front", *args[:-1], C.byref(args[-1]), C.byref(occ) if occ is not None else None,
+                         C.byref(rows) if rows is not None else None)
         elif "hod" in st:        # no front to ride with: the HOD's own kernel (n, b are there already)
             h = st.pop("hod")
             ctx.call_now("hmg_hod", nz, nm, h.h_par, h.d_zs, h.d_ms, h.d_log10mstar_thresh, h.d_nzm, h.d_bh, h.d_wm,

@@ -374,11 +374,14 @@ typedef struct {   /* hmg_power_batch's arguments after nk */
 } hmg_power_batch_desc;
 /* front: first stage of the sigma^2 contraction (hmg_sigma2_prepared's arguments; the partial sums stay
  * in the context until a massfn part consumes them) beside the halo stage and, optionally, the occupation
- * numbers of an HOD (stage HMG_HOD_OCCUPATIONS) - everything of a pass that needs inputs only.          */
+ * numbers of an HOD (stage HMG_HOD_OCCUPATIONS) and the row parameters of a Battaglia profile - everything
+ * of a pass that needs inputs only.                                                                       */
 int hmg_sigma2_halo_front(hmg_ctx* ctx, int nz, int nm, int nq, const double* d_PT, const double* d_kq,
                           const double* d_wq, const double* d_R, double taylor_switch,
                           const double* d_ms, const hmg_halo_stage_args* h_halo,
-                          const hmg_hod_part* h_hod_occupations /* or NULL */);
+                          const hmg_hod_part* h_hod_occupations /* or NULL */,
+                          const hmg_rows_part* h_rows /* or NULL: Battaglia row parameters from the M_200c, R_200c,
+                                                         r_vir this call's halo stage computes (same arrays) */);
 /* rows group: n(z,m), b(z,m) in 62-mass tiles | per-z chain (an HOD; not together with a massfn part, whose
  * n, b it would need) | Battaglia row parameters | analytic NFW rows.  A massfn part needs the partial sums
  * of the last hmg_sigma2_halo_front on this context with the same nz, nm, nq.                           */

@@ -8,8 +8,12 @@ for v in $VARS; do
   rocprofv3 --kernel-trace --stats -d gpurun_out/ktv_$v -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber --steps 30 "$@" > gpurun_out/ktv_$v.log 2>&1
   python3 - gpurun_out/ktv_$v/k_kernel_stats.csv "$v" "$PAT" <<'PY'
 import csv, sys
+tot = 0.0
 for r in csv.DictReader(open(sys.argv[1])):
-    if int(r["Calls"]) < 20 or (sys.argv[3] and sys.argv[3] not in r["Name"]): continue
+    if int(r["Calls"]) < 20: continue
+    tot += float(r["AverageNs"]) / 1e3
+    if sys.argv[3] and sys.argv[3] not in r["Name"]: continue
     print(f"{sys.argv[2]:8s} {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:60]}")
+print(f"{sys.argv[2]:8s} {tot:8.1f} us  sum of kernels per step")
 PY
 done
