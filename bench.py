@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_CYCLES = 4      # a wave64 fp64 VALU instruction occupies its SIMD-32 for 4 cycles
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
 PROFILE_DIR = os.path.join(REPO, "profiles", "r03")
-BRACKET_EVERY = 4         # kernel-level HIP events ride on every 4th timed step
+BRACKET_EVERY = int(os.environ.get("HMG_BENCH_BRACKET_EVERY", "8"))   # kernel-level HIP events ride on every 8th timed step
 
 
 def workload(nz=32, nm=512, nk=4096):
@@ -363,7 +363,7 @@ def main():
         spec.wait_gathered(); compute(); spec.gather()
     ctx.sync()
     use_graph = not args.no_graph and not args.stages
-    g_plain = g_brack = None
+    g_plain = g_brack = t_brack = None
     events_in_graph = False
     if use_graph:
         g_plain = ctx.capture(lambda: compute())
@@ -375,6 +375,12 @@ def main():
             events_in_graph = 0.0 < t < 100.0
         except nat.NativeError:
             events_in_graph = False
+        if not events_in_graph:
+            # They do not (ROCm 7.2): the bracketed steps are issued eagerly - as a recorded CALL LIST, not through
+            # the Python facade (85 us of host work per pass, which made every bracketed step of a 0.1 ms thin-slab
+            # pass host-bound and inflated ms_per_step by 10 %)
+            t_brack = ctx.trace(lambda: compute(brackets=True))
+            ctx.sync()
 
     kern_ms = {k: [] for k in BR}
     stage_ms = []
@@ -402,6 +408,8 @@ def main():
         spec.wait_gathered()
         if use_graph and (not bracketed or events_in_graph):
             ctx.replay(g_brack if bracketed else g_plain)
+        elif use_graph and t_brack is not None:
+            ctx.run_trace(t_brack)
         else:
             compute(brackets=bracketed, stages=bracketed and args.stages)
         spec.gather()
@@ -591,7 +599,8 @@ def main():
         "host_issue_ms_per_step": t_issue / K * 1e3, "preconditioning_steps": PRECONDITION,
         "launch_mode": ("hip-graph replay" if use_graph else "eager launches") + (", lanes" if args.lanes else ""),
         "kernel_events": f"HIP events around the three large kernels on every {BRACKET_EVERY}th timed step"
-                         + (" (graph event nodes)" if use_graph and events_in_graph else " (eager launches)"),
+                         + (" (graph event nodes)" if use_graph and events_in_graph else
+                            " (eager launches from a recorded call list)" if t_brack is not None else " (eager launches)"),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Config 3: zs={zs.size} ms={ms.size} ks={ks.size}, analytic NFW + "

@@ -307,6 +307,7 @@ class Context:
         self.device = int(device)
         self.capture_serial = 0       # changes at every capture begin/end: events recorded before are off limits
         self._deferred = []           # objects with stages queued for a grouped launch (HaloModel), in order
+        self._trace = None            # list of (name, args) while Context.trace records a launch-only sequence
 
     # deferred stages: a HaloModel queues the launch-only stages of a pass so that independent ones can
     # share a launch (hmg_group_*); ANY other native call of this context issues them first, so program
@@ -321,7 +322,28 @@ class Context:
 
     def call_now(self, name, *args):
         """A native call that does not flush the deferred stages (used while they are being issued)."""
+        if self._trace is not None:
+            self._trace.append((name, args))
         check(getattr(self.lib, name)(self.handle, *args))
+
+    # call lists: the native calls of a launch-only sequence (a pass), recorded once and re-issued without the
+    # Python facade in between - what a step that cannot be a HIP graph (event records with timestamps) uses so
+    # that the host stays ahead of a 0.1 ms pass.  Same restrictions as a capture: same buffers, no allocation.
+    def trace(self, fn):
+        self.flush()
+        self._trace = []
+        try:
+            fn()
+            self.flush()
+            return self._trace
+        finally:
+            self._trace = None
+
+    def run_trace(self, calls):
+        self.flush()
+        lib, h = self.lib, self.handle
+        for name, args in calls:
+            check(getattr(lib, name)(h, *args))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -388,6 +410,8 @@ class Context:
     def call(self, name, *args):
         if name not in self._NO_FLUSH:
             self.flush()
+        if self._trace is not None:
+            self._trace.append((name, args))
         check(getattr(self.lib, name)(self.handle, *args))
 
     # captured steps
