@@ -1077,7 +1077,7 @@ __device__ __forceinline__ double gnfw_rho_fast(double lt /* ln(x/xc) */, double
     return A * exp_fast(gamma * lt - EX * log1p_fast(ta));
 }
 
-template <int NT, int R, int MAXB>
+template <int NT, int R, int MAXB, bool SMALL = false>
 __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ twM, int M, int Ns, int twstep,
                                            unsigned magic, int keep) {
     // keep >= 0 (last pass only, Ns == M/R): butterfly j writes Z[j + t*Ns]; only Z[0..keep] and
@@ -1087,13 +1087,13 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
         const int j = threadIdx.x + b * NT;
-        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_load<R>(buf, twM, M, Ns, twstep, magic, j, v[b]);
+        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_load<R, SMALL>(buf, twM, M, Ns, twstep, magic, j, v[b]);
     }
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
         const int j = threadIdx.x + b * NT;
-        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_store<R>(buf, Ns, magic, j, v[b]);
+        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_store<R, SMALL>(buf, Ns, magic, j, v[b]);
     }
     __syncthreads();
 }
@@ -1135,18 +1135,43 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // are there anyway (red[17..23]: left-fill counter, jn, 1/(r_s(1+z)), k_lo, k_hi, 1/k_lo, u scale).
     const int z = row / A.nm;
     int* s_jn = reinterpret_cast<int*>(red + 18);
-    if (threadIdx.x == 0) {
-        *s_cnt = 0;
+    // The LAST wavefront works them out (in the truncated Battaglia rows it holds no non-zero sample, so it is the
+    // one with nothing to do in phase A); every lane computes the same values and lane 0 stores them.  With the
+    // hint arrays (ks ascending) the same wavefront also locates the end of the left-fill prefix - the first target
+    // wavenumber that is not below k_lo - by a 64-way search: each lane tests the last wavenumber of its segment,
+    // the number of lanes that see it below k_lo is the number of segments that lie in the prefix entirely, and the
+    // next segment holds the boundary (two dependent loads for nk <= 4096).  Phase D then fills [0, nleft)
+    // without loading or testing a wavenumber.
+    if (threadIdx.x >= NT - 64) {
+        const int lane = threadIdx.x & 63;
         const double isc0 = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));      // kout_j = kts[j] * isc
         const double klo0 = A.kts[1] * isc0;
         const double idk0 = 1.0 / klo0;
-        int jn0 = M;
+        int jn0 = M, nleft = 0;
         if (A.nconst) {
             const double tmax = A.ks[A.nk - 1] * idk0;
             if (tmax < (double)(M - 4)) jn0 = (int)tmax + 3;           // one spare mode for the rounding of tmax
+            int base = 0, end = A.nk;
+            for (;;) {
+                const int stp = (end - base + 63) >> 6;
+                const int first = base + lane * stp;
+                bool below = false;
+                if (first < end) {
+                    const int last = first + stp - 1;
+                    below = A.ks[last < end ? last : end - 1] < klo0;
+                }
+                base += __popcll(__ballot(below)) * stp;
+                if (base >= end) { base = end; break; }
+                if (stp == 1) break;
+                end = base + stp < end ? base + stp : end;
+            }
+            nleft = base;
         }
-        *s_jn = jn0;
-        red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
+        if (lane == 0) {
+            *s_cnt = nleft;
+            *s_jn = jn0;
+            red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
+        }
     }
 #if defined(HMG_ABL) && HMG_ABL == 6     // timing experiment: launch + row scalars, no integrand
     if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = Aamp + XC + AL + EX + cm + ln_xc;
@@ -1210,13 +1235,13 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // next pass's twiddle between the two halves of a pass.  Both lengthen live ranges under the 64-VGPR
     // cap of 8 waves/SIMD: 0.277 -> 0.315 ms.)
     if constexpr (SPECM == 2500) {
-        constexpr unsigned mg4 = 4294967296ull / 4 + 1, mg20 = 4294967296ull / 20 + 1, mg100 = 4294967296ull / 100 + 1,
-                           mg500 = 4294967296ull / 500 + 1;
-        if (!pruned) fused_pass<NT, 4, MAXB>(buf, A.twM, 2500, 1, 625, 0u, -1);
-        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 4, 125, mg4, -1);
-        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 20, 25, mg20, -1);
-        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 100, 5, mg100, -1);
-        fused_pass<NT, 5, 1>(buf, A.twM, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
+        // butterfly indices stay below 1024: the 24-bit index arithmetic of ldsfft.hpp (div_ns)
+        constexpr unsigned mg4 = small_magic(4), mg20 = small_magic(20), mg100 = small_magic(100), mg500 = small_magic(500);
+        if (!pruned) fused_pass<NT, 4, MAXB, true>(buf, A.twM, 2500, 1, 625, 0u, -1);
+        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 4, 125, mg4, -1);
+        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 20, 25, mg20, -1);
+        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 100, 5, mg100, -1);
+        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
     } else
     for (int ps = pruned ? 1 : 0; ps < A.plan.npass; ++ps) {
         const int R = A.plan.radix[ps], Ns = A.plan.ns[ps], tws = A.plan.twstep[ps];
@@ -1276,15 +1301,30 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     const double pf = A.post ? A.post[row] : 1.0;
     const double u1 = u[0];
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
-    int nleft = 0;     // wave-uniform count of left-filled targets seen by this wavefront
-    for (int i = threadIdx.x; i < A.nk; i += NT) {
+    // with the hint arrays the left fill [0, nleft) is a plain fill in 16-byte stores (no wavenumber is loaded or
+    // tested) and the interpolation starts at the 64-aligned index below nleft, so that its stores stay on whole
+    // 512-byte wavefront segments; without them (ks in any order) every target is tested
+    const int nleft = A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0;
+    if (nleft > 0) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const double c = u1 * pf;
+        const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);     // row start not 16-B aligned
+        const int npair = (nleft - head) >> 1;
+        v2d* __restrict__ d2 = reinterpret_cast<v2d*>(dst + head);
+        const v2d cc = {c, c};
+        for (int q = threadIdx.x; q < npair; q += NT) __builtin_nontemporal_store(cc, &d2[q]);
+        if (threadIdx.x == 0) {
+            if (head) __builtin_nontemporal_store(c, &dst[0]);
+            if ((nleft - head) & 1) __builtin_nontemporal_store(c, &dst[nleft - 1]);
+        }
+    }
+    for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
+        if (i < nleft) continue;
         // (requesting the next trip's wavenumber one trip ahead was measured: +-0, the other wavefronts of the
         // workgroup already cover the load)
         const double k = A.ks[i];
         double val;
-        const bool left = k < k_lo;
-        if (A.nconst) nleft += __popcll(__ballot(left));
-        if (left) {
+        if (k < k_lo) {            // only without the hint arrays
             val = u1;
         } else if (k > k_hi) {
             val = 0.0;
@@ -1297,14 +1337,9 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         }
         __builtin_nontemporal_store(val * pf, &dst[i]);
     }
-    if (A.nconst) {
-        // ks ascending: the number of targets below k_lo is the index of the first one that is not
-        if ((threadIdx.x & 63) == 0 && nleft) atomicAdd(s_cnt, nleft);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            A.nconst[row] = *s_cnt;
-            A.cconst[row] = u1 * pf;
-        }
+    if (A.nconst && threadIdx.x == 0) {
+        A.nconst[row] = nleft;
+        A.cconst[row] = u1 * pf;
     }
 }
 template <int NT, int MAXB, int MAXP, int SPECM>

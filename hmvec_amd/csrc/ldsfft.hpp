@@ -50,6 +50,28 @@ HMG_HD unsigned fast_div(unsigned j, unsigned magic) {
 #endif
 }
 
+// The same for butterflies of a short transform (j < 1024, d <= 1024) with magic = ceil(2^20 / d): the product
+// stays below 2^30 and the operands below 2^24, so that the GPU's full-rate 24-bit multiplier does it
+// (v_mul_hi_u32 / v_mul_lo_u32 run at a quarter of that rate).  Exact: j * (magic * d - 2^20) < j * d <= 2^20.
+HMG_HD unsigned mul_small(unsigned a, unsigned b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
+constexpr unsigned small_magic(unsigned d) { return d == 1 ? 0u : ((1u << 20) + d - 1) / d; }
+template <bool SMALL>
+HMG_HD unsigned div_ns(unsigned j, unsigned magic) {
+    if constexpr (SMALL) return magic ? mul_small(j, magic) >> 20 : j;
+    else return fast_div(j, magic);
+}
+template <bool SMALL>
+HMG_HD int mul_idx(int a, int b) {
+    if constexpr (SMALL) return (int)mul_small((unsigned)a, (unsigned)b);
+    else return a * b;
+}
+
 // Factor M into radices 5,4,3,2 (as few passes as possible: 4 before 2), then order the passes by
 // ascending radix.  The first pass is the one the fused profile kernel can skip when the input is
 // zero beyond sample M/R0 (truncated profiles): the smallest radix gives the loosest condition and
@@ -134,16 +156,17 @@ HMG_HD void dft_small<5>(cplx* v) {
 //   store: buf[(j div Ns)*Ns*R + k + t*Ns] = DFT_R(v)[t]
 // Every load of a pass must precede every store of that pass (barrier on the GPU).
 // (Ns, twstep, magic) are the pass's entries of FftPlanDev.
-template <int R>
+// SMALL: j < 1024, Ns <= 1024 and magic = small_magic(Ns) (see div_ns).
+template <int R, bool SMALL = false>
 HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twstep, unsigned magic, int j, cplx* v) {
-    const int k = j - (int)fast_div((unsigned)j, magic) * Ns;      // j mod Ns
+    const int k = j - mul_idx<SMALL>((int)div_ns<SMALL>((unsigned)j, magic), Ns);      // j mod Ns
     const int stride = M / R;
     v[0] = buf[j];
     // one table read (w = W^(k M/(Ns R))); the higher powers by complex multiplication
     // (<= 3 products, a few ulp) instead of R-1 dependent trips to the L2-resident table.
     // k == 0 is not special-cased: its twiddle is twM[0] = 1 exactly, and a branch would make
     // every wavefront that holds such a lane walk both paths.
-    const cplx w1 = twM[k * twstep];
+    const cplx w1 = twM[mul_idx<SMALL>(k, twstep)];
     cplx w = w1;
 #pragma unroll
     for (int t = 1; t < R; ++t) {
@@ -151,12 +174,12 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twste
         if (t + 1 < R) w = cmul(w, w1);
     }
 }
-template <int R>
+template <int R, bool SMALL = false>
 HMG_HD void pass_store(cplx* buf, int Ns, unsigned magic, int j, cplx* v) {
     dft_small<R>(v);
-    const int q = (int)fast_div((unsigned)j, magic);               // j div Ns
-    const int k = j - q * Ns;
-    const int j0 = q * Ns * R + k;
+    const int q = (int)div_ns<SMALL>((unsigned)j, magic);          // j div Ns
+    const int k = j - mul_idx<SMALL>(q, Ns);
+    const int j0 = mul_idx<SMALL>(q, Ns * R) + k;
 #pragma unroll
     for (int t = 0; t < R; ++t) buf[j0 + t * Ns] = v[t];
 }

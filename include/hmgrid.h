@@ -250,7 +250,9 @@ int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_st
 int hmg_profile_fft_logx(hmg_ctx* ctx, int nxs, const double* d_xs, double* d_logxs);
 /* d_nconst / d_cconst (both or neither): constant-prefix hint of every output row for hmg_tracer -
  * the number of leading target wavenumbers below the row's first FFT mode and the value they all
- * receive.  Only meaningful when d_ks is ascending (the caller's responsibility).               */
+ * receive.  With the hint arrays d_ks MUST be ascending (the caller's responsibility): the kernel finds the end of
+ * that prefix by a search and fills it without loading or testing its wavenumbers; for a target grid in any
+ * other order pass NULL for both.                                                                */
 
 /* ---- H1-H3: HOD occupations ----------------------------------------------------------------
  * Replaces avg_Nc/avg_Ns/avg_NsNsm1/avg_NcNs, Mstellar_halo/Mhalo_stellar, get_ngal/get_bg
