@@ -1077,7 +1077,7 @@ __device__ __forceinline__ double gnfw_rho_fast(double lt /* ln(x/xc) */, double
     return A * exp_fast(gamma * lt - EX * log1p_fast(ta));
 }
 
-template <int NT, int R, int MAXB, bool SMALL = false>
+template <int NT, int R, int MAXB, bool SMALL = false, int NIN = R>
 __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ twM, int M, int Ns, int twstep,
                                            unsigned magic, int keep) {
     // keep >= 0 (last pass only, Ns == M/R): butterfly j writes Z[j + t*Ns]; only Z[0..keep] and
@@ -1087,13 +1087,13 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
         const int j = threadIdx.x + b * NT;
-        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_load<R, SMALL>(buf, twM, M, Ns, twstep, magic, j, v[b]);
+        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_load<R, SMALL, NIN>(buf, twM, M, Ns, twstep, magic, j, v[b]);
     }
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
         const int j = threadIdx.x + b * NT;
-        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_store<R, SMALL>(buf, Ns, magic, j, v[b]);
+        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_store<R, SMALL, NIN>(buf, Ns, magic, j, v[b]);
     }
     __syncthreads();
 }
@@ -1238,7 +1238,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         // butterfly indices stay below 1024: the 24-bit index arithmetic of ldsfft.hpp (div_ns)
         constexpr unsigned mg4 = small_magic(4), mg20 = small_magic(20), mg100 = small_magic(100), mg500 = small_magic(500);
         if (!pruned) fused_pass<NT, 4, MAXB, true>(buf, A.twM, 2500, 1, 625, 0u, -1);
-        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 4, 125, mg4, -1);
+        // behind the pruned first pass slot i of the row holds sample i/4: a butterfly of this pass reads slots
+        // j + 500 t, and those with t >= 3 are zero when the row is zero from sample 1500/4 on (cmax < 3 at xmax = 20)
+        if (pruned && A.xs[2 * 375] > cm) fused_pass<NT, 5, 1, true, 3>(buf, A.twM, 2500, 4, 125, mg4, -1);
+        else fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 4, 125, mg4, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 20, 25, mg20, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 100, 5, mg100, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);

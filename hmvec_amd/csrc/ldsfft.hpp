@@ -151,32 +151,56 @@ HMG_HD void dft_small<5>(cplx* v) {
     v[3] = csub(m2, n2);
 }
 
+// DFT_5 of (v0, v1, v2, 0, 0): dft_small<5> with the terms that are exactly zero left out - the same products and
+// sums in the same order, so the same values (a butterfly of the pass behind a pruned first pass sees this input
+// when the row is zero beyond sample 3M/(R0 R1): see the fused profile kernel).
+HMG_HD void dft5_lead3(cplx* v) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+    const cplx t1 = v[1], t2 = v[2];
+    const cplx m1 = {v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y};
+    const cplx m2 = {v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y};
+    const cplx n1 = cmul_mi(cplx{s1 * t1.x + s2 * t2.x, s1 * t1.y + s2 * t2.y});
+    const cplx n2 = cmul_mi(cplx{s2 * t1.x - s1 * t2.x, s2 * t1.y - s1 * t2.y});
+    v[0] = cadd(v[0], cadd(t1, t2));
+    v[1] = cadd(m1, n1);
+    v[4] = csub(m1, n1);
+    v[2] = cadd(m2, n2);
+    v[3] = csub(m2, n2);
+}
+
 // One Stockham pass of radix R on butterfly j (0 <= j < M/R), sub-transform size Ns so far:
 //   load:  v[t] = buf[j + t*M/R] * W_M^(t * k * M/(Ns*R)),  k = j mod Ns  (no integer division: fast_div)
 //   store: buf[(j div Ns)*Ns*R + k + t*Ns] = DFT_R(v)[t]
 // Every load of a pass must precede every store of that pass (barrier on the GPU).
 // (Ns, twstep, magic) are the pass's entries of FftPlanDev.
 // SMALL: j < 1024, Ns <= 1024 and magic = small_magic(Ns) (see div_ns).
-template <int R, bool SMALL = false>
+// NIN < R: only the first NIN inputs of every butterfly are non-zero (R == 5, NIN == 3 only).
+template <int R, bool SMALL = false, int NIN = R>
 HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twstep, unsigned magic, int j, cplx* v) {
     const int k = j - mul_idx<SMALL>((int)div_ns<SMALL>((unsigned)j, magic), Ns);      // j mod Ns
     const int stride = M / R;
     v[0] = buf[j];
     // one table read (w = W^(k M/(Ns R))); the higher powers by complex multiplication
-    // (<= 3 products, a few ulp) instead of R-1 dependent trips to the L2-resident table.
+    // (<= 3 products, a few ulp) instead of R-1 trips to the L2-resident table (measured on MI355X in round 3,
+    // all powers read from the table: the fused profile kernel goes from 0.204 to 0.245 ms - a 16-byte-per-lane
+    // load occupies the CU's one vector-memory return path for 16 cycles, the 12 multiply-adds it saves cost 48
+    // cycles on one of four SIMDs).
     // k == 0 is not special-cased: its twiddle is twM[0] = 1 exactly, and a branch would make
     // every wavefront that holds such a lane walk both paths.
     const cplx w1 = twM[mul_idx<SMALL>(k, twstep)];
     cplx w = w1;
 #pragma unroll
-    for (int t = 1; t < R; ++t) {
+    for (int t = 1; t < NIN; ++t) {
         v[t] = cmul(buf[j + t * stride], w);
-        if (t + 1 < R) w = cmul(w, w1);
+        if (t + 1 < NIN) w = cmul(w, w1);
     }
 }
-template <int R, bool SMALL = false>
+template <int R, bool SMALL = false, int NIN = R>
 HMG_HD void pass_store(cplx* buf, int Ns, unsigned magic, int j, cplx* v) {
-    dft_small<R>(v);
+    static_assert(NIN == R || (R == 5 && NIN == 3), "only the 3-of-5 butterfly exists");
+    if constexpr (NIN == R) dft_small<R>(v);
+    else dft5_lead3(v);
     const int q = (int)div_ns<SMALL>((unsigned)j, magic);          // j div Ns
     const int k = j - mul_idx<SMALL>(q, Ns);
     const int j0 = mul_idx<SMALL>(q, Ns * R) + k;
