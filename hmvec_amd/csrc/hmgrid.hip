@@ -74,10 +74,11 @@ struct FftPlan {
     size_t work_bytes = 0;
 };
 
+namespace hmg { struct UnpackTw; }
 struct FusedPlan {
     hmg::FftPlanDev plan;
     hmg::cplx* twM = nullptr;
-    double2* twN = nullptr;
+    hmg::UnpackTw* twN = nullptr;
     int maxb = 0, maxp = 0;
 };
 
@@ -1045,12 +1046,18 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
 // 2*8*nxs + 2*16*(nxs/2+1) bytes per row through the memory system (3.2 GB at Config 3).
 // Used when nxs is even, nxs/2 factors into 5/4/3/2 and fits LDS; otherwise hmg_profile_fft
 // falls back to the chunked rocFFT path.
+// per-mode constants of the unpack step, one 32-byte load: the rotation of the packed-real transform and the
+// reciprocals that turn Im F_j into u_j = -Im F_j step / (kt_j mnorm) with kt_j = j kt_1 (the modes of an FFT
+// sit on a uniform grid: np.fft.rfftfreq) - a table value and one product instead of a reciprocal per mode.
+struct alignas(32) UnpackTw {
+    double co, si, rj, rmj;
+};
 struct FusedArgs {
     FftPlanDev plan;
     int nxs, nm, nk, do_norm;
     const double* xs;
     const cplx* twM;     // exp(-2 pi i t / M), t < M
-    const double2* twN;  // (cos, sin)(2 pi j / nxs), j <= M/2
+    const UnpackTw* twN; // (cos, sin)(2 pi j / nxs), 1/j, 1/(M-j) for j <= M/2
     const double* kts;
     const double *amp, *xc, *alpha, *expo;
     double amp_c, xc_c, alpha_c, expo_c, gamma, step;
@@ -1077,7 +1084,7 @@ __device__ __forceinline__ double gnfw_rho_fast(double lt /* ln(x/xc) */, double
     return A * exp_fast(gamma * lt - EX * log1p_fast(ta));
 }
 
-template <int NT, int R, int MAXB, bool SMALL = false, int NIN = R>
+template <int NT, int R, int MAXB, bool SMALL = false, int NIN = R, int SRC_SHIFT = 0>
 __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ twM, int M, int Ns, int twstep,
                                            unsigned magic, int keep) {
     // keep >= 0 (last pass only, Ns == M/R): butterfly j writes Z[j + t*Ns]; only Z[0..keep] and
@@ -1087,7 +1094,7 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
         const int j = threadIdx.x + b * NT;
-        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_load<R, SMALL, NIN>(buf, twM, M, Ns, twstep, magic, j, v[b]);
+        if (j < nb && (keep < 0 || j <= keep || j >= nb - keep)) pass_load<R, SMALL, NIN, SRC_SHIFT>(buf, twM, M, Ns, twstep, magic, j, v[b]);
     }
     __syncthreads();
 #pragma unroll
@@ -1171,6 +1178,7 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
             *s_cnt = nleft;
             *s_jn = jn0;
             red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
+            red[23] = 1.0 / A.kts[1];
         }
     }
 #if defined(HMG_ABL) && HMG_ABL == 6     // timing experiment: launch + row scalars, no integrand
@@ -1199,12 +1207,13 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
 #endif
         const cplx y = cplx{xv.x * r0, xv.y * r1};
-        if (pruned) {
+        if (pruned && !SPECM) {
             // the R0 copies go out in an order rotated by lane/4: with t the same in every lane, lanes l and l+4
             // (64 B apart) hit the same LDS banks and every one of these 16-B stores takes two passes
             const int rot = (threadIdx.x >> 2);
-            for (int t = 0; t < R0; ++t) buf[R0 * p + (SPECM ? ((t + rot) & 3) : (t + rot) % R0)] = y;
+            for (int t = 0; t < R0; ++t) buf[R0 * p + (t + rot) % R0] = y;
         } else {
+            // (the compile-time plan replicates nothing: its second pass reads slot i as sample i >> 2)
             buf[p] = y;
         }
         if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
@@ -1240,8 +1249,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         if (!pruned) fused_pass<NT, 4, MAXB, true>(buf, A.twM, 2500, 1, 625, 0u, -1);
         // behind the pruned first pass slot i of the row holds sample i/4: a butterfly of this pass reads slots
         // j + 500 t, and those with t >= 3 are zero when the row is zero from sample 1500/4 on (cmax < 3 at xmax = 20)
-        if (pruned && A.xs[2 * 375] > cm) fused_pass<NT, 5, 1, true, 3>(buf, A.twM, 2500, 4, 125, mg4, -1);
-        else fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 4, 125, mg4, -1);
+        if (pruned) {
+            if (A.xs[2 * 375] > cm) fused_pass<NT, 5, 1, true, 3, 2>(buf, A.twM, 2500, 4, 125, mg4, -1);
+            else fused_pass<NT, 5, 1, true, 5, 2>(buf, A.twM, 2500, 4, 125, mg4, -1);
+        } else fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 4, 125, mg4, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 20, 25, mg20, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 100, 5, mg100, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
@@ -1264,7 +1275,7 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
 #endif
     // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm for the reachable modes
     // j = 1..jn, into smem[0..jn-1]
-    const double sc = -A.step / mnorm;            // u_j = Im F_j * this / kt_j
+    const double sc = -A.step / mnorm * red[23];  // u_j = Im F_j * this / j   (kt_j = j kt_1)
     double ua[MAXP], ub[MAXP];
     const int half = M / 2;
 #pragma unroll
@@ -1273,11 +1284,11 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         const bool hi = (M - j <= jn);                 // the mirrored mode M-j is reachable too
         if (j <= half && (j <= jn || hi)) {
             const cplx zj = buf[j], zmj = buf[M - j];
-            const double2 w = A.twN[j];
+            const UnpackTw w = A.twN[j];
             double fa, fb;
-            unpack_imag_pair(zj, zmj, w.x, w.y, fa, fb);
-            ua[b] = fa * sc * rcp_fast(A.kts[j]);
-            ub[b] = hi ? fb * sc * rcp_fast(A.kts[M - j]) : 0.0;
+            unpack_imag_pair(zj, zmj, w.co, w.si, fa, fb);
+            ua[b] = fa * sc * w.rj;
+            ub[b] = hi ? fb * sc * w.rmj : 0.0;
         }
     }
     __syncthreads();
@@ -3299,14 +3310,15 @@ static int get_fused_plan(hmg_ctx* c, int nxs, FusedPlan** out) {
         return 0;
     }
     std::vector<cplx> twM(M);
-    std::vector<double2> twN(M / 2 + 1);
+    std::vector<UnpackTw> twN(M / 2 + 1);
     const long double twopi = 6.283185307179586476925286766559L;
     for (int t = 0; t < M; ++t) twM[t] = cplx{(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
-    for (int j = 0; j <= M / 2; ++j) twN[j] = make_double2((double)cosl(twopi * j / nxs), (double)sinl(twopi * j / nxs));
+    for (int j = 0; j <= M / 2; ++j)
+        twN[j] = UnpackTw{(double)cosl(twopi * j / nxs), (double)sinl(twopi * j / nxs), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
     HIP_TRY(hipMalloc((void**)&P.twM, twM.size() * sizeof(cplx)));
-    HIP_TRY(hipMalloc((void**)&P.twN, twN.size() * sizeof(double2)));
+    HIP_TRY(hipMalloc((void**)&P.twN, twN.size() * sizeof(UnpackTw)));
     HIP_TRY(hipMemcpy(P.twM, twM.data(), twM.size() * sizeof(cplx), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(P.twN, twN.data(), twN.size() * sizeof(double2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.twN, twN.data(), twN.size() * sizeof(UnpackTw), hipMemcpyHostToDevice));
     auto res = c->fused.emplace(nxs, P);
     *out = &res.first->second;
     return 0;

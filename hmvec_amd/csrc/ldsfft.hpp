@@ -176,11 +176,13 @@ HMG_HD void dft5_lead3(cplx* v) {
 // (Ns, twstep, magic) are the pass's entries of FftPlanDev.
 // SMALL: j < 1024, Ns <= 1024 and magic = small_magic(Ns) (see div_ns).
 // NIN < R: only the first NIN inputs of every butterfly are non-zero (R == 5, NIN == 3 only).
-template <int R, bool SMALL = false, int NIN = R>
+// SRC_SHIFT = s: input slot i is read from buf[i >> s] - the pass behind a pruned radix-2^s first pass, whose
+// output slot i is sample i >> s, reads the samples themselves (nothing has to be replicated first).
+template <int R, bool SMALL = false, int NIN = R, int SRC_SHIFT = 0>
 HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twstep, unsigned magic, int j, cplx* v) {
     const int k = j - mul_idx<SMALL>((int)div_ns<SMALL>((unsigned)j, magic), Ns);      // j mod Ns
     const int stride = M / R;
-    v[0] = buf[j];
+    v[0] = buf[j >> SRC_SHIFT];
     // one table read (w = W^(k M/(Ns R))); the higher powers by complex multiplication
     // (<= 3 products, a few ulp) instead of R-1 trips to the L2-resident table (measured on MI355X in round 3,
     // all powers read from the table: the fused profile kernel goes from 0.204 to 0.245 ms - a 16-byte-per-lane
@@ -192,7 +194,7 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twste
     cplx w = w1;
 #pragma unroll
     for (int t = 1; t < NIN; ++t) {
-        v[t] = cmul(buf[j + t * stride], w);
+        v[t] = cmul(buf[(j + t * stride) >> SRC_SHIFT], w);
         if (t + 1 < NIN) w = cmul(w, w1);
     }
 }

@@ -17,6 +17,29 @@ __global__ void flat_read(const double2* __restrict__ a, size_t n, double* out) 
 }
 
 // grid (nk/128, nz), block 512: wave w reads rows m = w, w+8, ... of its z, chunk blockIdx.x
+// write-side reference points: the producers of the tensors (analytic NFW rows, fused profile rows) store one
+// (nk) row per workgroup, 8 B per lane, non-temporal; values differ per element (an all-equal fill lets the chip
+// clock higher)
+__global__ __launch_bounds__(256) void row_write8(double* __restrict__ t, int nk) {
+    double* row = t + (size_t)blockIdx.x * nk;
+    const double base = 1.0 / (1.0 + blockIdx.x);
+    for (int i = threadIdx.x; i < nk; i += 256) __builtin_nontemporal_store(base + 1e-6 * i, &row[i]);
+}
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void row_write16(double* __restrict__ t, int nk) {
+    v2d_t* row = reinterpret_cast<v2d_t*>(t + (size_t)blockIdx.x * nk);
+    const double base = 1.0 / (1.0 + blockIdx.x);
+    for (int i = threadIdx.x; i < nk / 2; i += 256) {
+        const v2d_t v = {base + 2e-6 * i, base + 2e-6 * i + 1e-6};
+        __builtin_nontemporal_store(v, &row[i]);
+    }
+}
+__global__ __launch_bounds__(256) void row_write8_plain(double* __restrict__ t, int nk) {
+    double* row = t + (size_t)blockIdx.x * nk;
+    const double base = 1.0 / (1.0 + blockIdx.x);
+    for (int i = threadIdx.x; i < nk; i += 256) row[i] = base + 1e-6 * i;
+}
+
 __global__ __launch_bounds__(512) void shaped_read(const double* __restrict__ t0, const double* __restrict__ t1,
                                                    int nm, int nk, double* out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, z = blockIdx.y;
@@ -65,7 +88,7 @@ int main() {
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double bytes = 2.0 * n * 8;
-    for (int variant = 0; variant < 8; ++variant) {
+    for (int variant = 0; variant < 11; ++variant) {
         float best = 1e30f;
         for (int rep = 0; rep < 12; ++rep) {
             CK(hipEventRecord(e0));
@@ -85,18 +108,26 @@ int main() {
                 hipLaunchKernelGGL(shaped_read_work<32>, dim3(nk / 128, nz), dim3(512), 0, 0, t0, t1, nm, nk, out);
             } else if (variant == 6) {
                 hipLaunchKernelGGL(shaped_read_work<32>, dim3(nk / 128, nz), dim3(512), 60000, 0, t0, t1, nm, nk, out);
-            } else {
+            } else if (variant == 7) {
                 hipLaunchKernelGGL(shaped_read_work<64>, dim3(nk / 128, nz), dim3(512), 0, 0, t0, t1, nm, nk, out);
+            } else if (variant == 8) {
+                hipLaunchKernelGGL(row_write8, dim3(nz * nm), dim3(256), 0, 0, t0, nk);
+            } else if (variant == 9) {
+                hipLaunchKernelGGL(row_write16, dim3(nz * nm), dim3(256), 0, 0, t0, nk);
+            } else {
+                hipLaunchKernelGGL(row_write8_plain, dim3(nz * nm), dim3(256), 0, 0, t0, nk);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 1 && ms < best) best = ms;
         }
-        const char* name[8] = {"flat grid-stride read, 2048 blocks", "flat grid-stride read, 8192 blocks",
+        const char* name[11] = {"flat grid-stride read, 2048 blocks", "flat grid-stride read, 8192 blocks",
                                "power_batch access shape, no math", "shape + 2 FMA/iter, 2 blocks/CU (LDS pad)",
                                "shape + 32 FMA/iter", "shape + 64 FMA/iter", "shape + 64 FMA/iter, 2 blocks/CU",
-                               "shape + 128 FMA/iter"};
-        printf("%-40s %.4f ms  %.0f GB/s\n", name[variant], best, bytes / (best * 1e-3) / 1e9);
+                               "shape + 128 FMA/iter", "row write, 8 B/lane non-temporal (1 tensor)",
+                               "row write, 16 B/lane non-temporal (1 tensor)", "row write, 8 B/lane plain (1 tensor)"};
+        const double moved = variant >= 8 ? bytes / 2 : bytes;
+        printf("%-44s %.4f ms  %.0f GB/s\n", name[variant], best, moved / (best * 1e-3) / 1e9);
     }
     return 0;
 }
