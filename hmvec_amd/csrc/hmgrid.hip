@@ -1194,8 +1194,12 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     const int R0 = SPECM ? 4 : A.plan.radix[0];
     const int stride0 = M / R0;
     const bool pruned = (SPECM || A.plan.npass > 1) && A.xs[2 * stride0] > cm;   // xs is increasing
+    // compile-time plan: when the row is zero from sample 375 on, the pass behind the pruned one reads samples
+    // 0..374 only (3-of-5 butterflies, below) and the rest of the row need not even be cleared
+    const bool lead3 = SPECM == 2500 && pruned && A.xs[2 * 375] > cm;
+    const int pend = lead3 ? 375 : (pruned ? stride0 : M);
     double acc = 0.0;
-    for (int p = threadIdx.x; p < (pruned ? stride0 : M); p += NT) {
+    for (int p = threadIdx.x; p < pend; p += NT) {
         const int j = 2 * p;
         const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
         double r0 = 0.0, r1 = 0.0;
@@ -1250,7 +1254,7 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         // behind the pruned first pass slot i of the row holds sample i/4: a butterfly of this pass reads slots
         // j + 500 t, and those with t >= 3 are zero when the row is zero from sample 1500/4 on (cmax < 3 at xmax = 20)
         if (pruned) {
-            if (A.xs[2 * 375] > cm) fused_pass<NT, 5, 1, true, 3, 2>(buf, A.twM, 2500, 4, 125, mg4, -1);
+            if (lead3) fused_pass<NT, 5, 1, true, 3, 2>(buf, A.twM, 2500, 4, 125, mg4, -1);
             else fused_pass<NT, 5, 1, true, 5, 2>(buf, A.twM, 2500, 4, 125, mg4, -1);
         } else fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 4, 125, mg4, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 20, 25, mg20, -1);
@@ -1332,24 +1336,29 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
             if ((nleft - head) & 1) __builtin_nontemporal_store(c, &dst[nleft - 1]);
         }
     }
-    for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
-        if (i < nleft) continue;
-        // (requesting the next trip's wavenumber one trip ahead was measured: +-0, the other wavefronts of the
-        // workgroup already cover the load)
-        const double k = A.ks[i];
-        double val;
-        if (k < k_lo) {            // only without the hint arrays
-            val = u1;
-        } else if (k > k_hi) {
-            val = 0.0;
-        } else {
-            int j = (int)(k * inv_dk);
-            j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
-            const double fr = fma(k, inv_dk, -(double)j);
-            const double y0 = u[j - 1], y1 = u[j];
-            val = fma(y1 - y0, fr, y0);
+    auto interp = [&](double k) {
+        int j = (int)(k * inv_dk);
+        j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
+        const double fr = fma(k, inv_dk, -(double)j);
+        const double y0 = u[j - 1], y1 = u[j];
+        return fma(y1 - y0, fr, y0);
+    };
+    if (A.nconst) {
+        // behind the prefix every target is at or above k_lo (ks ascending)
+        for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
+            if (i < nleft) continue;
+            // (requesting the next trip's wavenumber one trip ahead was measured: +-0, the other wavefronts of
+            // the workgroup already cover the load)
+            const double k = A.ks[i];
+            const double val = k > k_hi ? 0.0 : interp(k);
+            __builtin_nontemporal_store(val * pf, &dst[i]);
         }
-        __builtin_nontemporal_store(val * pf, &dst[i]);
+    } else {
+        for (int i = threadIdx.x; i < A.nk; i += NT) {
+            const double k = A.ks[i];
+            const double val = k < k_lo ? u1 : (k > k_hi ? 0.0 : interp(k));
+            __builtin_nontemporal_store(val * pf, &dst[i]);
+        }
     }
     if (A.nconst && threadIdx.x == 0) {
         A.nconst[row] = nleft;
