@@ -60,6 +60,9 @@ HMG_FM_HD double log_fast(double x) {
 
 // e^y for |y| < 700 (outside, ldexp saturates to 0 / inf as exp would).  k = rint(y/ln 2),
 // r = y - k ln 2 in two FMA steps, degree-13 Taylor polynomial on |r| <= ln2/2 (remainder 4e-18).
+// CLAMP = false: the caller guarantees |y| < 1e9 (the exponent then fits an int without the two extra
+// instructions; results are the same).
+template <bool CLAMP = true>
 HMG_FM_HD double exp_fast(double y) {
     const double kd = rint(y * 1.44269504088896338700);
     double r = fma(-kd, 6.93147180559945286227e-01, y);
@@ -77,8 +80,8 @@ HMG_FM_HD double exp_fast(double y) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double kc = fmin(fmax(kd, -2000.0), 2000.0);
-    return ldexp(p, (int)kc);
+    if constexpr (CLAMP) return ldexp(p, (int)fmin(fmax(kd, -2000.0), 2000.0));
+    else return ldexp(p, (int)kd);
 }
 
 // ln(1 + a) for finite a >= 0: ln w with w = fl(1 + a), plus the first-order correction for the
@@ -88,5 +91,10 @@ HMG_FM_HD double log1p_fast(double a) {
     const double c = a - (w - 1.0);
     return log_fast(w) + c * fm_rcp(w);
 }
+
+// ln(1 + a) for finite a >= 0 to 1.2e-16 ABSOLUTE (plus log_fast's 2 ulp): ln of the rounded sum, without the
+// correction term - for an exponent of an exp, where only the absolute error counts (the integrand's
+// (1 + t^alpha)^(-e) = exp(-e ln(1 + t^alpha)) takes a relative error e * 1.2e-16 from it).
+HMG_FM_HD double log1p_abs(double a) { return log_fast(1.0 + a); }
 
 }  // namespace hmg

@@ -1080,8 +1080,9 @@ __global__ void logx_kernel(int n, const double* __restrict__ xs, double* __rest
 // ~100 VALU ops per sample instead of ~190 with the device library's and ~700 with three pow().
 __device__ __forceinline__ double gnfw_rho_fast(double lt /* ln(x/xc) */, double A, double AL, double EX,
                                                 double gamma) {
-    const double ta = exp_fast(fmin(AL * lt, 700.0));
-    return A * exp_fast(gamma * lt - EX * log1p_fast(ta));
+    // (|exponents| stay far below 1e9: no clamp; the logarithm's absolute error is what the outer exp sees)
+    const double ta = exp_fast<false>(fmin(AL * lt, 700.0));
+    return A * exp_fast<false>(gamma * lt - EX * log1p_abs(ta));
 }
 
 template <int NT, int R, int MAXB, bool SMALL = false, int NIN = R, int SRC_SHIFT = 0>
