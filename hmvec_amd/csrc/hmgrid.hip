@@ -1227,11 +1227,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         }
     }
     // mass norm: wavefront sums (DPP), one LDS exchange, and EVERY thread adds the eight partials itself in
-    // wave order - no second reduction stage, no third barrier.  The two barriers also publish buf and the
-    // row scalars thread 0 wrote.
+    // wave order - no second reduction stage.  The barrier also publishes buf and the row scalars the last
+    // wavefront wrote (red[0..7] are written nowhere else, so nothing has to be waited for before).
     {
         const double ws = wave_sum(acc);
-        __syncthreads();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
         __syncthreads();
     }
