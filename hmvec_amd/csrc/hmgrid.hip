@@ -291,7 +291,10 @@ __device__ __forceinline__ void sigma2_mfma_block(int bx, int seg, int bz, int n
         }
     };
     // window values (branch-free: Taylor and trigonometric forms both evaluated, selected by kR; the library
-    // sincos is only called if some lane has kR >= 1e9) and the MFMA accumulation
+    // sincos is only called if some lane has kR >= 1e9) and the MFMA accumulation.  (Round 3: skipping the
+    // trigonometric form on trips whose 64 values all lie below the Taylor switch - a quarter of the trips of a
+    // default grid - was measured and is slower, 19.2 -> 20.4 us at nz = 4, 28.7 -> 29.6 at nz = 32: the branch
+    // splits the four interleaved evaluations the scheduler overlaps.)
     auto consume = [&](const Trip& T) {
         double a[4];
 #pragma unroll
@@ -639,6 +642,17 @@ __global__ void nfw_series_kernel(int rows, const double* __restrict__ cs, doubl
     nfw_series_row(cs[row], acoef + (size_t)row * NFW_ROW);
 }
 
+// Order in which the row workgroups of a launch take the masses of a redshift: heaviest first.  Workgroups are
+// dispatched in index order and the rows of the heavy end of the mass grid are the expensive ones in both tensor
+// producers (NFW: most of their wavenumbers are on the Si/Ci branch; Battaglia: many FFT modes are reachable), so
+// ascending order leaves the most expensive rows for the tail of the launch.  Measured on MI355X (rows group +
+// profile group): 58.9 -> 55.3 us on a 4-redshift slab, 97.9 -> 96.1 at nz = 8, +-0 at nz = 32; folding the mass
+// axis (light half ascending, heavy half descending) and mass-major order over all redshifts were no better.
+__device__ __forceinline__ int row_order(int r, int nm) {
+    const int z = r / nm, i = r - z * nm;
+    return z * nm + (nm - 1 - i);
+}
+
 // ktile = k values per workgroup (a multiple of the block size)
 // 46 VGPRs, no scratch (with machine LICM off: see the Makefile); the bound only keeps it under 64.
 #ifndef HMG_NFW_OCC
@@ -665,8 +679,9 @@ __device__ __forceinline__ void nfw_rows(const SiciTable* __restrict__ T, const 
     // (+4 %), half tiles (+40 %) and 128 threads per row (+-0): a workgroup's fixed cost is the latency of
     // its scalar loads (row constants, series coefficients), not instructions
     const int ktiles = (nk + ktile - 1) / ktile;
-    const int row = blk / ktiles;  // z*nm + m
-    const int k_lo = (blk - row * ktiles) * ktile;
+    const int brow = blk / ktiles;
+    const int row = row_order(brow, nm);  // z*nm + m
+    const int k_lo = (blk - brow * ktiles) * ktile;
     const int k_hi = min(nk, k_lo + ktile);
     const int z = row / nm;
     const double c = cs[row];
@@ -2073,6 +2088,10 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs
     // waits for its own decision.  The scheduling barriers keep hipcc from sinking the early loads back
     // down to their first use.
     int i = 0;
+    // (Round 3, thin z-slabs: a four-stage version of this pipeline - three bins of tensor loads in flight - was
+    // measured on the 16-wavefront shapes: 25.9 -> 26.0 us at nz = 4, 39.9 -> 40.7 at nz = 8.  What a wavefront
+    // waits for there is the scalar load of the next bin's coefficient row, which cannot run ahead: two rows do
+    // not fit the scalar register file.)
     vec_t ta[NT], tb[NT];
     Hint ha, hb;
     load_hint(ha, bin(0));
@@ -2321,7 +2340,7 @@ __global__ __launch_bounds__(512, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_
         chain_row<512>(C, b, smem);
         return;
     }
-    profile_fused_row<512, MAXB, MAXP, SPECM>(A, b - nchain, smem);
+    profile_fused_row<512, MAXB, MAXP, SPECM>(A, row_order(b - nchain, A.nm), smem);
 }
 
 // ---------------------------------------------------------------- N1: Limber integral
