@@ -2091,7 +2091,10 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs
     // (Round 3, thin z-slabs: a four-stage version of this pipeline - three bins of tensor loads in flight - was
     // measured on the 16-wavefront shapes: 25.9 -> 26.0 us at nz = 4, 39.9 -> 40.7 at nz = 8.  What a wavefront
     // waits for there is the scalar load of the next bin's coefficient row, which cannot run ahead: two rows do
-    // not fit the scalar register file.)
+    // not fit the scalar register file.  Staging each wavefront's rows in LDS a chunk ahead - vector loads in
+    // flight during the previous chunk, coefficients read by broadcast ds_read_b64 - was also built: bit-identical
+    // and slower, 26.4 -> 39.8 us at nz = 4 and 41.4 -> 45.0 at nz = 8, since 29 LDS reads per bin and wavefront
+    // occupy the LDS pipe for longer than the scalar round trip they replace.)
     vec_t ta[NT], tb[NT];
     Hint ha, hb;
     load_hint(ha, bin(0));
