@@ -379,13 +379,44 @@ def test_compile_time_plan_equals_run_time_plan(monkeypatch):
         h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
         h.add_battaglia_profile("e20", nxs=5000, xmax=20)          # truncation at ~2.6 of 20: first pass pruned
         h.add_battaglia_profile("e8", nxs=5000, xmax=8)            # 2.6 > 8/4: not pruned
-        h.add_battaglia_pres_profile("y", nxs=5000, xmax=20)
-        out[generic] = (h.uk_profiles["e20"].copy(), h.uk_profiles["e8"].copy(), h.pk_profiles["y"].copy())
+        h.add_battaglia_profile("e12", nxs=5000, xmax=12)          # pruned, but not zero from sample 375 on: the
+        h.add_battaglia_pres_profile("y", nxs=5000, xmax=20)       # full butterfly behind the pruned pass
+        out[generic] = (h.uk_profiles["e20"].copy(), h.uk_profiles["e8"].copy(), h.pk_profiles["y"].copy(),
+                        h.uk_profiles["e12"].copy())
     monkeypatch.delenv("HMG_FUSED_GENERIC")
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
     o = oracle_for(h, zs, ks, ms, 5000, 8)
     assert np.max(np.abs(out["0"][1] - o.uk_profiles["electron"])) < 1e-12
+    o = oracle_for(h, zs, ks, ms, 5000, 12)
+    assert np.max(np.abs(out["0"][3] - o.uk_profiles["electron"])) < 1e-12
+
+
+@pytest.mark.parametrize("nk,klo,khi", [(301, 0.5, 8.0), (64, 1e-4, 1e-2), (130, 40.0, 900.0), (257, 1e-3, 3000.0)])
+def test_left_fill_prefix_of_every_length(nk, klo, khi):
+    """The fused profile kernel finds the end of np.interp's left-fill prefix of a row by a search and writes the
+    prefix as a plain fill: rows whose targets all lie below the first FFT mode (prefix = the whole row), rows with
+    none below it, odd row lengths (every other row starts off a 16-byte boundary) and targets beyond the last mode."""
+    import hmvec_amd as hm
+    zs = np.array([0.1, 0.9, 2.4])
+    ms = np.geomspace(2e10, 1e17, 37)
+    ks = np.geomspace(klo, khi, nk)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", nxs=5000, xmax=20)
+    h.add_battaglia_profile("e1000", nxs=1000, xmax=20)            # run-time plan
+    ue = h.uk_profiles["electron"]
+    n = h.uk_profiles.hint("electron")[0].numpy().view(np.int32)[:zs.size * ms.size].reshape(zs.size, ms.size)
+    c = h.uk_profiles.hint("electron")[1].numpy()
+    for iz in range(zs.size):
+        for im in range(ms.size):
+            k = int(n[iz, im])
+            assert 0 <= k <= nk and np.all(ue[iz, im, :k] == c[iz, im]), (iz, im)
+    if (nk, klo) == (301, 0.5):
+        assert n.min() == 0 and n.max() == nk                   # both extremes occur on this grid
+    o = oracle_for(h, zs, ks, ms, 5000, 20)
+    assert np.max(np.abs(ue - o.uk_profiles["electron"])) < 1e-12
+    o = oracle_for(h, zs, ks, ms, 1000, 20)
+    assert np.max(np.abs(h.uk_profiles["e1000"] - o.uk_profiles["electron"])) < 1e-12
 
 
 @pytest.mark.parametrize("nz,nm", [(3, 7), (2, 64), (5, 130), (1, 65)])
