@@ -47,3 +47,49 @@ extern "C" int ldsfft_rfft_imag(const double* y, int n, int nthreads, double* im
     }
     return 0;
 }
+
+// The compile-time plan of the fused profile kernel for nxs = 5000 (M = 2500, passes 4,5,5,5,5), sequenced as the
+// kernel sequences it for a row that is zero from packed sample `nz_from` on:
+//   nz_from <= 375: pruned first pass, samples 0..374 only, 3-of-5 butterflies reading the compact source;
+//   nz_from <= 625: pruned first pass, full butterflies reading the compact source;
+//   otherwise     : all five passes.
+// Everything runs the 24-bit index arithmetic (SMALL).  Returns the same Im F_j as ldsfft_rfft_imag.
+template <int R, int NIN, int SRC>
+static void run_spec_pass(std::vector<cplx>& buf, const std::vector<cplx>& tw, int Ns, int twstep, int nthreads) {
+    const int M = 2500, nb = M / R;
+    const unsigned mg = small_magic((unsigned)Ns);
+    std::vector<cplx> regs((size_t)nb * R);
+    for (int tid = 0; tid < nthreads; ++tid)
+        for (int j = tid; j < nb; j += nthreads)
+            pass_load<R, true, NIN, SRC>(buf.data(), tw.data(), M, Ns, twstep, mg, j, &regs[(size_t)j * R]);
+    for (int tid = 0; tid < nthreads; ++tid)
+        for (int j = tid; j < nb; j += nthreads) pass_store<R, true, NIN>(buf.data(), Ns, mg, j, &regs[(size_t)j * R]);
+}
+extern "C" int ldsfft_rfft_imag_spec2500(const double* y, int nz_from, int nthreads, double* imF /* 2501 */) {
+    const int M = 2500, n = 5000;
+    std::vector<cplx> tw(M);
+    const long double twopi = 6.283185307179586476925286766559L;
+    for (int t = 0; t < M; ++t) tw[t] = {(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
+    // stale values where the kernel leaves LDS untouched: a wrong read shows up in the result
+    std::vector<cplx> buf(M, cplx{1.0e30, -1.0e30});
+    const bool pruned = nz_from <= 625, lead3 = nz_from <= 375;
+    const int pend = lead3 ? 375 : (pruned ? 625 : M);
+    for (int m = 0; m < pend; ++m) buf[m] = {y[2 * m], y[2 * m + 1]};
+    if (!pruned) run_spec_pass<4, 4, 0>(buf, tw, 1, 625, nthreads);
+    if (lead3) run_spec_pass<5, 3, 2>(buf, tw, 4, 125, nthreads);
+    else if (pruned) run_spec_pass<5, 5, 2>(buf, tw, 4, 125, nthreads);
+    else run_spec_pass<5, 5, 0>(buf, tw, 4, 125, nthreads);
+    run_spec_pass<5, 5, 0>(buf, tw, 20, 25, nthreads);
+    run_spec_pass<5, 5, 0>(buf, tw, 100, 5, nthreads);
+    run_spec_pass<5, 5, 0>(buf, tw, 500, 1, nthreads);
+    imF[0] = 0.0;
+    imF[M] = 0.0;
+    for (int j = 1; j <= M / 2; ++j) {
+        const double th = (double)(twopi * j / n);
+        double a, b;
+        unpack_imag_pair(buf[j], buf[M - j], cos(th), sin(th), a, b);
+        imF[j] = a;
+        imF[M - j] = b;
+    }
+    return 0;
+}

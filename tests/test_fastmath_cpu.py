@@ -81,15 +81,22 @@ def test_host_builds_are_clean_under_asan_ubsan(tmp_path, src, entry):
     if entry == "fm_log":
         body = """
 extern "C" void fm_log(const double*, int, double*); extern "C" void fm_exp(const double*, int, double*);
-extern "C" void fm_log1p(const double*, int, double*);
+extern "C" void fm_log1p(const double*, int, double*); extern "C" void fm_exp_nc(const double*, int, double*);
+extern "C" void fm_log1p_abs(const double*, int, double*);
 int main() { std::vector<double> x(4097), o(4097); for (int i = 0; i < 4097; ++i) x[i] = 1e-3 * (i + 1);
   fm_log(x.data(), 4097, o.data()); fm_exp(x.data(), 4097, o.data()); fm_log1p(x.data(), 4097, o.data());
+  fm_exp_nc(x.data(), 4097, o.data()); fm_log1p_abs(x.data(), 4097, o.data());
   return o[7] > 0 ? 0 : 1; }"""
     else:
         body = """
 extern "C" int ldsfft_rfft_imag(const double*, int, int, double*);
+extern "C" int ldsfft_rfft_imag_spec2500(const double*, int, int, double*);
 int main() { int rc = 0; for (int n : {4, 12, 600, 5000, 20000}) { std::vector<double> y(n), o(n / 2 + 1);
   for (int i = 0; i < n; ++i) y[i] = 1.0 / (1 + i); rc |= ldsfft_rfft_imag(y.data(), n, 512, o.data()); }
+  // the compile-time plan's sequences: 3-of-5 butterflies on the compact source, full ones on it, all five passes
+  for (int nz_from : {1, 375, 376, 625, 626, 2500}) { std::vector<double> y(5000, 0.0), o(2501);
+    for (int i = 0; i < 2 * nz_from && i < 5000; ++i) y[i] = 1.0 / (1 + i);
+    rc |= ldsfft_rfft_imag_spec2500(y.data(), nz_from, 512, o.data()); }
   return rc; }"""
     main.write_text("#include <vector>\n" + body)
     exe = tmp_path / "san"

@@ -19,6 +19,8 @@ def lib(tmp_path_factory):
     lib = ctypes.CDLL(str(out))
     lib.ldsfft_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.ldsfft_rfft_imag.restype = ctypes.c_int
+    lib.ldsfft_rfft_imag_spec2500.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.ldsfft_rfft_imag_spec2500.restype = ctypes.c_int
     return lib
 
 
@@ -43,3 +45,22 @@ def test_odd_length_rejected(lib):
     y = np.ones(15)
     out = np.zeros(8)
     assert lib.ldsfft_rfft_imag(y.ctypes.data, 15, 64, out.ctypes.data) == 1
+
+
+@pytest.mark.parametrize("nonzero", [1, 300, 674, 749, 750, 900, 1249, 1250, 1251, 3000, 5000])
+def test_compile_time_plan_sequence_with_truncated_rows(lib, nonzero):
+    """The nxs = 5000 plan as the fused kernel sequences it (hmgrid.hip, SPECM = 2500): rows that are zero from real
+    sample `nonzero` on take the pruned first pass with the compact source and - below sample 750 - the 3-of-5 butterfly
+    over samples 0..374 only; the rest of the buffer holds garbage there.  Same Im F as the run-time plan, to rounding."""
+    rng = np.random.default_rng(nonzero)
+    y = np.zeros(5000)
+    y[:nonzero] = rng.standard_normal(nonzero) * np.exp(-np.linspace(0, 3, nonzero))
+    nz_from = (nonzero + 1) // 2                      # first packed sample that is zero
+    out, gen = np.zeros(2501), np.zeros(2501)
+    assert lib.ldsfft_rfft_imag_spec2500(y.ctypes.data, nz_from, 512, out.ctypes.data) == 0
+    assert lib.ldsfft_rfft_imag(y.ctypes.data, 5000, 512, gen.ctypes.data) == 0
+    ref = np.fft.rfft(y)
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(out - ref.imag)) < 4e-15 * scale * np.log2(5000)
+    # pruning only drops terms that are exactly zero: the two sequences agree as numbers
+    assert np.array_equal(out, gen)
