@@ -231,7 +231,9 @@ int hmg_profile_rows_from_mvir(hmg_ctx* ctx, int kind, int nz, int nm, const dou
  * strict x>cmax truncation).  Any of d_amp/d_xc/d_alpha/d_expo may be NULL meaning the
  * constant given in *_const.  d_xs [nxs] and d_kts [nxs/2+1] are the x grid
  * (linspace(0,xmax,nxs+1)[1:]) and the rfftfreq(nxs,fft_step)*2pi grid, built by the caller;
- * fft_step = (xs[-1]-xs[0])/nxs (hmvec/fft.py:45-47).
+ * fft_step = (xs[-1]-xs[0])/nxs (hmvec/fft.py:45-47).  d_kts must be that uniform mode grid,
+ * kts[j] = j * kts[1]: the in-LDS transform forms 1/kt_j as (1/j) / kt_1 and brackets the target
+ * wavenumbers by division with the mode spacing.
  * out[z,m,k] *= d_post[z,m] if d_post != NULL (pressure prefactor, hmvec.py:316).          */
 int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_step,
                     const double* d_xs, const double* d_kts,
