@@ -1153,9 +1153,9 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // low-mass rows (large k_lo) need a few dozen of the M modes, so the unpack and the last FFT
     // pass are cut down to those.  max(ks) is only known without a search when ks is ascending,
     // which is the caller's promise that comes with the hint arrays (include/hmgrid.h).
-    // These row scalars are the same for all 512 threads and cost a few divisions: thread 0 works them out
-    // while the others start on the integrand, and they travel through LDS behind the barriers that
-    // are there anyway (red[17..23]: left-fill counter, jn, 1/(r_s(1+z)), k_lo, k_hi, 1/k_lo, u scale).
+    // These row scalars are the same for all 512 threads and cost a few divisions: one wavefront works them out
+    // while the others start on the integrand, and they travel through LDS behind the barrier that is there
+    // anyway (red[17..23]: length of the left-fill prefix, jn, 1/(r_s(1+z)), k_lo, k_hi, 1/k_lo, 1/kt_1).
     const int z = row / A.nm;
     int* s_jn = reinterpret_cast<int*>(red + 18);
     // The LAST wavefront works them out (in the truncated Battaglia rows it holds no non-zero sample, so it is the
