@@ -1249,13 +1249,19 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
         __syncthreads();
     }
-    double tot = red[0];
+    // The first wavefront adds the eight partials in wave order and forms the one number the rest of the row needs
+    // from the norm: the scale of the unpack step, u_j = Im F_j * (-step / (mnorm kt_1)) / j.  It travels through
+    // red[24] behind the barriers of the FFT passes (a division and seven additions that 448 threads used to repeat).
+    if (threadIdx.x < 64) {
+        double tot = red[0];
 #pragma unroll
-    for (int w = 1; w < NT / 64; ++w) tot += red[w];
-    const double mnorm = A.do_norm ? tot : 1.0;
+        for (int w = 1; w < NT / 64; ++w) tot += red[w];
+        const double mnorm = A.do_norm ? tot : 1.0;
+        if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
+    }
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
 #if defined(HMG_ABL) && (HMG_ABL == 1 || HMG_ABL == 4)     // timing experiments only: stop after phase A
-    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + mnorm;
+    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[0];
     return;
 #endif
     // ---- phase B: in-place Stockham FFT of length M
@@ -1289,12 +1295,12 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
     }
 #if defined(HMG_ABL) && HMG_ABL == 2     // stop after phase B
-    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + mnorm;
+    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[24];
     return;
 #endif
     // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm for the reachable modes
     // j = 1..jn, into smem[0..jn-1]
-    const double sc = -A.step / mnorm * red[23];  // u_j = Im F_j * this / j   (kt_j = j kt_1)
+    const double sc = red[24];                    // u_j = Im F_j * this / j   (kt_j = j kt_1)
     double ua[MAXP], ub[MAXP];
     const int half = M / 2;
 #pragma unroll
