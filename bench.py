@@ -144,7 +144,7 @@ def _cpu_inputs(zs, ks, p):
                              h_of_z_zs=cos.h_of_z(zs))
 
 
-def _cpu_pass(ci, z, ms, ks, p, nxs):
+def _cpu_pass(ci, z, ms, ks, p, nxs, xmax=20.0):
     """One pass of the oracle over the redshifts z: per-stage seconds and the six spectra."""
     from hmvec_amd.params import battaglia_defaults
     from oracle import hmref
@@ -153,7 +153,7 @@ def _cpu_pass(ci, z, ms, ks, p, nxs):
     t.append(time.perf_counter())
     o.add_nfw_profile("nfw")
     t.append(time.perf_counter())
-    o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], nxs, 20)
+    o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], nxs, xmax)
     t.append(time.perf_counter())
     o.add_hod("g", mthresh=10 ** 10.5 + z * 0.0)
     t.append(time.perf_counter())
@@ -164,20 +164,21 @@ def _cpu_pass(ci, z, ms, ks, p, nxs):
 
 def _cpu_worker(job):
     """All-core variant: one process per z-slab, each running the single-threaded oracle."""
-    zs, ms, ks, nxs, reps = job
+    zs, ms, ks, nxs, reps = job[:5]
+    xmax = job[5] if len(job) > 5 else 20.0
     from hmvec_amd.params import default_params
     p = dict(default_params)
     ci = _cpu_inputs(zs, ks, p)
     best = None
     for _ in range(reps):
         t0 = time.perf_counter()
-        _cpu_pass(ci, zs, ms, ks, p, nxs)
+        _cpu_pass(ci, zs, ms, ks, p, nxs, xmax)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return best
 
 
-def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
+def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True, xmax=20.0):
     """The CPU oracle (numpy restatement of the reference, pinned by tests/golden) timed on this
     box's host cores, BEFORE the process touches the GPU: 1 warm-up + best of 3, per stage and
     total, on a z-subsample of the same workload (numpy elementwise ops, trapz, pocketfft and
@@ -195,7 +196,7 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
     stages = ["mass_function", "nfw", "battaglia_fft", "hod", "six_spectra"]
     runs = []
     for _ in range(4):                      # first one is the warm-up
-        st, out = _cpu_pass(ci, z, ms, ks, p, nxs)
+        st, out = _cpu_pass(ci, z, ms, ks, p, nxs, xmax)
         runs.append(st)
     runs = np.array(runs[1:])
     best = runs[np.argmin(runs.sum(axis=1))]
@@ -213,7 +214,7 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
         pools = None
     avail = len(os.sched_getaffinity(0))
     rec = dict(value=pts / best.sum(), unit="grid-points/s", cores=1, kind="port",
-               sample=f"{z.size} of {zs.size} redshifts x {ms.size} x {ks.size}, nxs={nxs}, 6 spectra; 1 warm-up + "
+               sample=f"{z.size} of {zs.size} redshifts x {ms.size} x {ks.size}, nxs={nxs}, xmax={xmax:g}, 6 spectra; 1 warm-up + "
                       f"best of 3 passes ({best.sum():.2f} s best, {runs.sum(axis=1).max():.2f} s worst), numpy single-thread",
                stages_s=dict(zip(stages, best.tolist())), seconds=float(best.sum()),
                full_grid_seconds_extrapolated=float(best.sum() * zs.size / z.size),
@@ -227,7 +228,7 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True):
                 nproc = cand
                 break
         per = zs.size // nproc
-        jobs = [(zs[i * per:(i + 1) * per], ms, ks, nxs, 2) for i in range(nproc)]
+        jobs = [(zs[i * per:(i + 1) * per], ms, ks, nxs, 2, xmax) for i in range(nproc)]
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(nproc) as pool:      # forked before any GPU initialisation
             bests = pool.map(_cpu_worker, jobs)
@@ -277,6 +278,9 @@ def main():
     ap.add_argument("--nm", type=int, default=512)
     ap.add_argument("--nk", type=int, default=4096)
     ap.add_argument("--nxs", type=int, default=5000)
+    ap.add_argument("--xmax", type=float, default=20.0,
+                    help="extent of the radial grid of the Battaglia profile (the reference's own callers also use "
+                         "xmax=50 with nxs=30000: examples/lensing_baryons.py:27, bin/tests.py:308)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches of every step one by one")
     ap.add_argument("--lanes", action="store_true",
@@ -308,7 +312,9 @@ def main():
     # ---- CPU baseline first: nothing in this process has touched the GPU yet
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(zs, ms, ks, min(args.cpu_sample_nz, zs.size), args.nxs)
+        # (the oracle materialises (nz_sample, nm, nxs) temporaries: fewer redshifts for the long radial grids)
+        nz_cpu = min(args.cpu_sample_nz, zs.size) if args.nxs <= 10000 else min(2, zs.size)
+        cpu = cpu_baseline(zs, ms, ks, nz_cpu, args.nxs, allcore=args.nxs <= 10000, xmax=args.xmax)
 
     if args.lanes:
         os.environ["HMG_LANES"] = "1"
@@ -326,7 +332,7 @@ def main():
 
     mthr = 10 ** 10.5 + zloc * 0.0
     h = hm.HaloModel(zloc, ks, ms=ms, accuracy="low", engine="analytic", ctx=ctx)
-    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=args.nxs)
+    h.add_battaglia_profile("electron", family="AGN", xmax=args.xmax, nxs=args.nxs)
     h.add_hod("g", mthresh=mthr)
     spec = ShardedSpectra(h, comm, zs.size, PAIRS)
     npair = len(PAIRS)
@@ -350,7 +356,7 @@ def main():
         h.add_nfw_profile("nfw", ignore_existing=True)
         mark(2)
         bracket("fft")
-        h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=args.nxs, ignore_existing=True)
+        h.add_battaglia_profile("electron", family="AGN", xmax=args.xmax, nxs=args.nxs, ignore_existing=True)
         mark(3)
         h.add_hod("g", mthresh=mthr, ignore_existing=True)
         mark(4)
@@ -446,7 +452,8 @@ def main():
 
     # ---- bytes: the implementation's own model and, for the default configuration,
     # the PMC counters of profiles/r03 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
-    default_cfg = (args.nz, args.nm, args.nk, args.nxs) == (32, 512, 4096, 5000) and world == 1 and not args.per_pair
+    default_cfg = ((args.nz, args.nm, args.nk, args.nxs, args.xmax) == (32, 512, 4096, 5000, 20.0) and world == 1
+                   and not args.per_pair)
     sha = nat.kernel_source_sha16()
     stale = []
 
@@ -603,8 +610,8 @@ def main():
                             " (eager launches from a recorded call list)" if t_brack is not None else " (eager launches)"),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"Config 3: zs={zs.size} ms={ms.size} ks={ks.size}, analytic NFW + "
-                               f"Battaglia AGN electron (nxs={args.nxs}, xmax=20) + HOD(mthresh=10^10.5), "
+        "config": {"workload": f"{'Config 3' if (args.nxs, args.xmax) == (5000, 20.0) else 'Config-3 grid, radial grid of the reference callers (examples/lensing_baryons.py:27)'}: zs={zs.size} ms={ms.size} ks={ks.size}, analytic NFW + "
+                               f"Battaglia AGN electron (nxs={args.nxs}, xmax={args.xmax:g}) + HOD(mthresh=10^10.5), "
                                f"6 auto/cross spectra 1h+2h, full path per step",
                    "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
                    "grid_points_per_step": pts},

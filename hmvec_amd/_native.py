@@ -259,7 +259,13 @@ class DeviceArray:
         return v
 
     def free(self):
-        """Hand the block back to the context's free list (no device synchronisation)."""
+        """Hand the block back to the context's free list (no device synchronisation).  The free list's
+        invariant - whatever still touches a freed block was enqueued earlier on the same stream - only holds
+        for work that HAS been enqueued.  Deferred stages hold raw addresses, so their owner must keep every
+        array they refer to alive until the queue is issued: HaloModel keeps them in its buffer pool and input
+        cache and issues the queue before it releases or replaces an entry of either (HaloModel._buf,
+        HaloModel._release_inputs).  Flushing here instead would issue the queue whenever any unrelated temporary
+        goes out of scope and split the grouped launches."""
         if self._owner is True and self.ptr and self.ctx is not None and self.ctx.handle:
             self.ctx.lib.hmg_free(self.ctx.handle, self.ptr)
         self.ptr = 0
@@ -321,7 +327,9 @@ class Context:
             self._deferred.pop(0)._flush()
 
     def call_now(self, name, *args):
-        """A native call that does not flush the deferred stages (used while they are being issued)."""
+        """A native call that does not flush the deferred stages (used while they are being issued).  Every
+        stream-affecting native call of this class goes through here, so that a recorded call list
+        (Context.trace) keeps lane switches, event records/waits and copies exactly as a capture does."""
         if self._trace is not None:
             self._trace.append((name, args))
         check(getattr(self.lib, name)(self.handle, *args))
@@ -366,7 +374,8 @@ class Context:
 
     def upload(self, arr):
         a = np.ascontiguousarray(arr, dtype=np.float64)
-        d = self.empty(a.shape)          # a fresh block: no queued stage can refer to it
+        d = self.empty(a.shape)          # (a recycled block: its last owner released it, and owners of queued
+                                         # stages issue the queue before they release anything - DeviceArray.free)
         check(self.lib.hmg_memcpy_h2d(self.handle, d.ptr, a.ctypes.data, a.nbytes))
         return d
 
@@ -374,12 +383,14 @@ class Context:
         """Overwrite DeviceArray ``dst`` with a host array (stream-ordered behind everything queued so far)."""
         self.flush()
         a = np.ascontiguousarray(arr, dtype=np.float64)
+        if self._trace is not None:
+            raise NativeError("Context.write inside Context.trace: a recorded call list cannot own host data")
         check(self.lib.hmg_memcpy_h2d(self.handle, dst.ptr, a.ctypes.data, a.nbytes))
 
     def copy(self, src):
         self.flush()
         d = self.empty(src.shape)
-        check(self.lib.hmg_memcpy_d2d(self.handle, d.ptr, src.ptr, src.nbytes))
+        self.call_now("hmg_memcpy_d2d", d.ptr, src.ptr, src.nbytes)
         return d
 
     def sync(self):
@@ -388,17 +399,17 @@ class Context:
 
     def record(self, slot):
         self.flush()
-        check(self.lib.hmg_event_record(self.handle, slot))
+        self.call_now("hmg_event_record", slot)
 
     def lane(self, i):
         """Route subsequent launches to lane i (0 = main stream)."""
         self.flush()
-        check(self.lib.hmg_lane_set(self.handle, i))
+        self.call_now("hmg_lane_set", i)
 
     def wait(self, slot):
         """Current lane waits for the event last recorded in `slot`."""
         self.flush()
-        check(self.lib.hmg_event_wait(self.handle, slot))
+        self.call_now("hmg_event_wait", slot)
 
     def elapsed_ms(self, s0, s1):
         ms = C.c_double()
@@ -440,12 +451,12 @@ class Context:
 
     def replay(self, gid):
         self.flush()
-        check(self.lib.hmg_graph_launch(self.handle, gid))
+        self.call_now("hmg_graph_launch", gid)
 
     def copy_to_pinned(self, pinned, src):
         """Asynchronous D2H of DeviceArray ``src`` into PinnedArray ``pinned`` on the current lane."""
         self.flush()
-        check(self.lib.hmg_memcpy_d2h_async(self.handle, pinned.ptr, src.ptr, src.nbytes))
+        self.call_now("hmg_memcpy_d2h_async", pinned.ptr, src.ptr, src.nbytes)
 
 
 _default_ctx = {}

@@ -1061,12 +1061,7 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
 // 2*8*nxs + 2*16*(nxs/2+1) bytes per row through the memory system (3.2 GB at Config 3).
 // Used when nxs is even, nxs/2 factors into 5/4/3/2 and fits LDS; otherwise hmg_profile_fft
 // falls back to the chunked rocFFT path.
-// per-mode constants of the unpack step, one 32-byte load: the rotation of the packed-real transform and the
-// reciprocals that turn Im F_j into u_j = -Im F_j step / (kt_j mnorm) with kt_j = j kt_1 (the modes of an FFT
-// sit on a uniform grid: np.fft.rfftfreq) - a table value and one product instead of a reciprocal per mode.
-struct alignas(32) UnpackTw {
-    double co, si, rj, rmj;
-};
+// (UnpackTw - the per-mode constants of the unpack step, one 32-byte load - lives in ldsfft.hpp)
 struct FusedArgs {
     FftPlanDev plan;
     int nxs, nm, nk, do_norm;
@@ -1390,6 +1385,230 @@ template <int NT, int MAXB, int MAXP, int SPECM>
 __global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_fused_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     profile_fused_row<NT, MAXB, MAXP, SPECM>(A, blockIdx.x, smem);
+}
+
+// ---------------------------------------------------------------- K45p: long radial grids with short support
+// nxs = 30000 / 40000 - what the reference's own callers pass (examples/lensing_baryons.py:27 and bin/tests.py:308:
+// add_battaglia_profile(xmax=50, nxs=30000); hmvec/params.py:59-60: numeric NFW, nxs = 40000, xmax = 200) - do not
+// fit LDS as one packed row (M = nxs/2 complex = 240-320 KB), but the profile is cut at cmax << xmax: only the first
+// P0 = ceil(#{x_n <= cmax} / 2) packed samples are non-zero (820 of 15000 for the gas profile at xmax = 50).  With
+// LP >= P0, M = R LP, the transform is R transforms of length LP of the row times W_M^{rp} (ldsfft.hpp, "pruned
+// decomposition"): one workgroup per (z,m) row keeps the P0 samples in LDS, transforms the residues r and R - r
+// side by side with the compile-time plan of length LP, unpacks the pair on the spot into u_j (a per-row scratch
+// line in HBM/L2: up to M modes do not fit LDS either) and interpolates as the fused kernel does.  Nothing of
+// length nxs is ever written: the rocFFT route this replaces moves 2*8*nxs + 2*16*(nxs/2+1) bytes per row.
+struct PrunedArgs {
+    FusedArgs F;          // the row description (F.plan is not used)
+    int M, R;             // packed length nxs/2 = R * LP
+    const cplx* twB;      // exp(-2 pi i t / M), t < M
+    const cplx* twL;      // exp(-2 pi i t / LP), t < LP
+    double* u;            // [rows of this launch][M]: u_j at [j-1]
+    int* fault;           // set when a row's support turns out longer than LP (stale support bound)
+    int row0;             // first row of this launch
+};
+
+template <int NT, int LP, int PS>
+__device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* __restrict__ twL, int nbuf, int keep) {
+    if constexpr (PS < SubPass<LP, 0>::P.npass) {
+        using S = SubPass<LP, PS>;
+        constexpr int MAXB = (2 * S::nb + NT - 1) / NT;
+        cplx v[MAXB][S::R];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            const int jj = threadIdx.x + b * NT;
+            if (sub_pass_active<LP, PS>(jj, nbuf, keep)) sub_pass_load<LP, PS>(buf, twL, jj, v[b]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            const int jj = threadIdx.x + b * NT;
+            if (sub_pass_active<LP, PS>(jj, nbuf, keep)) sub_pass_store<LP, PS>(buf, jj, v[b]);
+        }
+        __syncthreads();
+        pruned_passes<NT, LP, PS + 1>(buf, twL, nbuf, keep);
+    }
+}
+
+template <int NT, int LP>
+__device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row, double* smem) {
+    const FusedArgs& A = G.F;
+    // dynamic LDS: [0, LP) cplx = the packed samples of the row, [LP, 3 LP) = the two transform buffers, then 32
+    // doubles of scalars laid out as in profile_fused_row
+    cplx* src = reinterpret_cast<cplx*>(smem);
+    cplx* buf = src + LP;
+    double* red = smem + 6 * (size_t)LP;
+    int* s_cnt = reinterpret_cast<int*>(red + 17);
+    int* s_jn = reinterpret_cast<int*>(red + 18);
+    const int M = G.M, R = G.R, nxs = 2 * M;
+    const double Aamp = A.amp ? A.amp[row] : A.amp_c;
+    const double XC = A.xc ? A.xc[row] : A.xc_c;
+    const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
+    const double EX = A.expo ? A.expo[row] : A.expo_c;
+    const double cm = A.cmax[row];
+    const double ln_xc = (A.xc == nullptr && A.xc_c == 1.0) ? 0.0 : log_fast(XC);
+    const int z = row / A.nm;
+    double* __restrict__ dst = A.out + (size_t)row * A.nk;
+    // The plan was sized from a bound on the support (profile_support); a row that exceeds it cannot be transformed
+    // here: it is filled with NaN and the context's fault word is raised, which the next synchronising call reports.
+    if (!(A.xs[2 * LP] > cm)) {                    // (2 LP < nxs: R >= 2; xs increasing)
+        for (int i = threadIdx.x; i < A.nk; i += NT) dst[i] = __builtin_nan("");
+        if (threadIdx.x == 0) {
+            atomicOr(G.fault, 1);
+            if (A.nconst) { A.nconst[row] = 0; A.cconst[row] = __builtin_nan(""); }
+        }
+        return;
+    }
+    // row scalars and the end of the left-fill prefix: the last wavefront, as in profile_fused_row
+    if (threadIdx.x >= NT - 64) {
+        const int lane = threadIdx.x & 63;
+        const double isc0 = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));
+        const double klo0 = A.kts[1] * isc0;
+        const double idk0 = 1.0 / klo0;
+        int jn0 = M, nleft = 0;
+        if (A.nconst) {
+            const double tmax = A.ks[A.nk - 1] * idk0;
+            if (tmax < (double)(M - 4)) jn0 = (int)tmax + 3;
+            int base = 0, end = A.nk;
+            for (;;) {
+                const int stp = (end - base + 63) >> 6;
+                const int first = base + lane * stp;
+                bool below = false;
+                if (first < end) {
+                    const int last = first + stp - 1;
+                    below = A.ks[last < end ? last : end - 1] < klo0;
+                }
+                base += __popcll(__ballot(below)) * stp;
+                if (base >= end) { base = end; break; }
+                if (stp == 1) break;
+                end = base + stp < end ? base + stp : end;
+            }
+            nleft = base;
+        }
+        if (lane == 0) {
+            *s_cnt = nleft;
+            *s_jn = jn0;
+            red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
+            red[23] = 1.0 / A.kts[1];
+        }
+    }
+    // ---- phase A: the LP packed samples that can be non-zero, and the mass norm
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < LP; p += NT) {
+        const int j = 2 * p;
+        const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
+        double r0 = 0.0, r1 = 0.0;
+        if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
+        if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+        src[p] = cplx{xv.x * r0, xv.y * r1};
+        if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
+            const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
+            acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
+        }
+    }
+    {
+        const double ws = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+        double tot = red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) tot += red[w];
+        const double mnorm = A.do_norm ? tot : 1.0;
+        if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
+    }
+    const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
+    // ---- phase B + C: per group of residues {g, R - g}: twiddled copies, transforms, unpack into the scratch line
+    double* __restrict__ u = G.u + (size_t)(row - G.row0) * M;
+    constexpr int nb_last = SubPass<LP, SubPass<LP, 0>::P.npass - 1>::nb;
+    const int keep = pruned_keep(R, M, nb_last, jn);
+    for (int g = 0; g <= R / 2; ++g) {
+        if (!pruned_group_needed(R, M, g, jn)) break;          // (groups are needed in ascending order of g)
+        const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
+        for (int p = threadIdx.x; p < LP; p += NT) {
+            const cplx zp = src[p];
+            buf[p] = cmul(zp, G.twB[g * p]);
+            if (nbuf == 2) buf[LP + p] = cmul(zp, G.twB[s1 * p]);
+        }
+        __syncthreads();                                       // (also publishes red[24] before the first unpack)
+        pruned_passes<NT, LP, 0>(buf, G.twL, nbuf, keep);
+        const double sc = red[24];
+        pruned_unpack(buf, LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
+        if (nbuf == 2) pruned_unpack(buf, LP, R, M, s1, 1, 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
+        __syncthreads();                                       // the next group overwrites the buffers
+    }
+    if (threadIdx.x == 0) u[M - 1] = 0.0;                      // Nyquist mode: Im F_M == 0
+    __threadfence_block();
+    __syncthreads();                                           // u (global) is read by other threads below
+    // ---- phase D: as profile_fused_row, the modes read from the scratch line
+    const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
+    const double pf = A.post ? A.post[row] : 1.0;
+    const double u1 = u[0];
+    const int nleft = A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0;
+    if (nleft > 0) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const double c = u1 * pf;
+        const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+        const int npair = (nleft - head) >> 1;
+        v2d* __restrict__ d2 = reinterpret_cast<v2d*>(dst + head);
+        const v2d cc = {c, c};
+        for (int q = threadIdx.x; q < npair; q += NT) __builtin_nontemporal_store(cc, &d2[q]);
+        if (threadIdx.x == 0) {
+            if (head) __builtin_nontemporal_store(c, &dst[0]);
+            if ((nleft - head) & 1) __builtin_nontemporal_store(c, &dst[nleft - 1]);
+        }
+    }
+    auto interp = [&](double k) {
+        int j = (int)(k * inv_dk);
+        j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
+        const double fr = fma(k, inv_dk, -(double)j);
+        const double y0 = u[j - 1], y1 = u[j];
+        return fma(y1 - y0, fr, y0);
+    };
+    if (A.nconst) {
+        for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
+            if (i < nleft) continue;
+            const double k = A.ks[i];
+            const double val = k > k_hi ? 0.0 : interp(k);
+            __builtin_nontemporal_store(val * pf, &dst[i]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < A.nk; i += NT) {
+            const double k = A.ks[i];
+            const double val = k < k_lo ? u1 : (k > k_hi ? 0.0 : interp(k));
+            __builtin_nontemporal_store(val * pf, &dst[i]);
+        }
+    }
+    if (A.nconst && threadIdx.x == 0) {
+        A.nconst[row] = nleft;
+        A.cconst[row] = u1 * pf;
+    }
+}
+template <int LP> constexpr int pruned_occ() { return 3 * LP * 16 + 256 <= 160 * 1024 / 3 ? 6 : (3 * LP * 16 + 256 <= 80 * 1024 ? 4 : 2); }
+template <int NT, int LP>
+__global__ __launch_bounds__(NT, pruned_occ<LP>()) void profile_pruned_kernel(PrunedArgs G) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    profile_pruned_row<NT, LP>(G, G.row0 + blockIdx.x, smem);
+}
+
+// Upper bound of the support of a launch's rows: max over rows of the number of PACKED samples that can be non-zero,
+// ceil(#{n : x_n <= cmax[row]} / 2) (xs increasing; the mask of hmvec/fft.py:81 is strict, |x| > cmax).
+__global__ void profile_support_kernel(int rows, int nxs, const double* __restrict__ xs, const double* __restrict__ cmax,
+                                       int* __restrict__ out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    int p0 = 0;
+    if (row < rows) {
+        const double cm = cmax[row];
+        int lo = 0, hi = nxs;                       // first n with xs[n] > cm
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (xs[mid] > cm) hi = mid; else lo = mid + 1;
+        }
+        p0 = (lo + 1) >> 1;
+        if (!(cm == cm)) p0 = nxs;                  // NaN cmax: nothing is masked (|x| > NaN is false)
+    }
+    for (int off = 32; off; off >>= 1) p0 = max(p0, __shfl_xor(p0, off));
+    if ((threadIdx.x & 63) == 0 && p0 > 0) atomicMax(out, p0);
 }
 
 // ---------------------------------------------------------------- K7: HOD (H1-H3)

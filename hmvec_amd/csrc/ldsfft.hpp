@@ -76,33 +76,41 @@ HMG_HD int mul_idx(int a, int b) {
 // ascending radix.  The first pass is the one the fused profile kernel can skip when the input is
 // zero beyond sample M/R0 (truncated profiles): the smallest radix gives the loosest condition and
 // is the pass with the most butterflies.  Returns false if a larger prime remains.
-inline bool fft_make_plan(int M, FftPlanDev* p) {
-    p->M = M;
-    p->npass = 0;
+// constexpr: the kernels that know their length at compile time (SPECM, the sub-transforms of the pruned
+// long-grid route) evaluate the plan in the compiler, so that strides, twiddle steps and multipliers are immediates.
+constexpr bool fft_plan_fill(int M, FftPlanDev& p) {
+    p.M = M;
+    p.npass = 0;
     int rem = M;
     const int cand[4] = {5, 4, 3, 2};
     for (int ci = 0; ci < 4; ++ci) {
         const int r = cand[ci];
         while (rem % r == 0 && rem > 1) {
-            if (p->npass >= FFT_MAX_PASSES) return false;
-            p->radix[p->npass++] = r;
+            if (p.npass >= FFT_MAX_PASSES) return false;
+            p.radix[p.npass++] = r;
             rem /= r;
         }
     }
-    for (int i = 1; i < p->npass; ++i)          // insertion sort, ascending
-        for (int j = i; j > 0 && p->radix[j - 1] > p->radix[j]; --j) {
-            const int tmp = p->radix[j];
-            p->radix[j] = p->radix[j - 1];
-            p->radix[j - 1] = tmp;
+    for (int i = 1; i < p.npass; ++i)          // insertion sort, ascending
+        for (int j = i; j > 0 && p.radix[j - 1] > p.radix[j]; --j) {
+            const int tmp = p.radix[j];
+            p.radix[j] = p.radix[j - 1];
+            p.radix[j - 1] = tmp;
         }
     int Ns = 1;
-    for (int i = 0; i < p->npass; ++i) {
-        p->ns[i] = Ns;
-        p->twstep[i] = M / (Ns * p->radix[i]);
-        p->magic[i] = Ns == 1 ? 0u : (unsigned)(4294967296ull / (unsigned)Ns) + 1u;
-        Ns *= p->radix[i];
+    for (int i = 0; i < p.npass; ++i) {
+        p.ns[i] = Ns;
+        p.twstep[i] = M / (Ns * p.radix[i]);
+        p.magic[i] = Ns == 1 ? 0u : (unsigned)(4294967296ull / (unsigned)Ns) + 1u;
+        Ns *= p.radix[i];
     }
     return rem == 1 && M >= 2 && M < 65536;
+}
+inline bool fft_make_plan(int M, FftPlanDev* p) { return fft_plan_fill(M, *p); }
+constexpr FftPlanDev fft_plan_c(int M) {
+    FftPlanDev p{};
+    fft_plan_fill(M, p);
+    return p;
 }
 
 // In-place forward DFTs of size R (sign -).
@@ -218,6 +226,99 @@ HMG_HD void unpack_imag_pair(cplx zj, cplx zmj, double co, double si, double& im
     const double Q = si * (0.5 * (zj.y + zmj.y)) + co * (0.5 * (zj.x - zmj.x));
     imFj = P - Q;
     imFmj = -P - Q;
+}
+
+// ---- Long radial grids with short support: the pruned decomposition (hmvec/fft.py:56-94 with nxs = 30000 / 40000,
+// the lengths the reference's own callers use: examples/lensing_baryons.py:27, hmvec/params.py:59-60).
+// The packed row z_p (M = nxs/2 complex samples) does not fit LDS, but the profile is cut at cmax << xmax: z_p = 0
+// for p >= P0.  With LP >= P0, M = R LP:
+//     Z[r + R q] = sum_{p < LP} (z_p W_M^{r p}) W_LP^{q p},        r < R, q < LP
+// - R transforms of length LP of the row multiplied by W_M^{rp} - and the unpack step of the packed-real
+// transform pairs mode j = r + R q with M - j, which sits in residue (R - r) mod R at quotient LP - 1 - q
+// (LP - q for r == 0).  Residues r and R - r are therefore transformed together (two LDS buffers) and unpacked
+// on the spot; only the quotients that reach a needed mode j <= jn are kept.
+// per-mode constants of the unpack step, one 32-byte load: the rotation of the packed-real transform and the
+// reciprocals that turn Im F_j into u_j = -Im F_j step / (kt_j mnorm) with kt_j = j kt_1 (the modes of an FFT
+// sit on a uniform grid: np.fft.rfftfreq) - a table value and one product instead of a reciprocal per mode.
+struct alignas(32) UnpackTw {
+    double co, si, rj, rmj;      // (cos, sin)(2 pi j / N), 1/j, 1/(M-j)
+};
+struct PrunedPair {
+    int j;        // the mode, 1 <= j; its mirror is M - j
+    int qp;       // quotient of the mirror in the partner residue's transform
+};
+HMG_HD PrunedPair pruned_pair(int R, int LP, int s, int q) {
+    return PrunedPair{s + R * q, s == 0 ? LP - q : LP - 1 - q};
+}
+// One pass (index PS of the compile-time plan of length LP) over up to two buffers laid out back to back:
+// butterfly jj of the batch is butterfly jj mod nb of buffer jj / nb.
+template <int LP, int PS>
+struct SubPass {
+    static constexpr FftPlanDev P = fft_plan_c(LP);
+    static constexpr int R = P.radix[PS], Ns = P.ns[PS], tws = P.twstep[PS], nb = LP / R;
+    static constexpr bool SMALL = nb <= 1024 && Ns <= 1024;
+    static constexpr unsigned mg = SMALL ? small_magic((unsigned)Ns) : P.magic[PS];
+    static constexpr bool last = PS == P.npass - 1;
+};
+template <int LP, int PS>
+HMG_HD void sub_pass_load(const cplx* buf, const cplx* twL, int jj, cplx* v) {
+    using S = SubPass<LP, PS>;
+    const int b = jj >= S::nb ? 1 : 0, j = jj - b * S::nb;
+    pass_load<S::R, S::SMALL>(buf + b * LP, twL, LP, S::Ns, S::tws, S::mg, j, v);
+}
+template <int LP, int PS>
+HMG_HD void sub_pass_store(cplx* buf, int jj, cplx* v) {
+    using S = SubPass<LP, PS>;
+    const int b = jj >= S::nb ? 1 : 0, j = jj - b * S::nb;
+    pass_store<S::R, S::SMALL>(buf + b * LP, S::Ns, S::mg, j, v);
+}
+// butterfly jj of the last pass is needed when its buffer-local index is within `keep` of either end
+// (outputs q <= keep and q >= LP - keep: see fused_pass); keep < 0 keeps everything
+template <int LP, int PS>
+HMG_HD bool sub_pass_active(int jj, int nbuf, int keep) {
+    using S = SubPass<LP, PS>;
+    if (jj >= nbuf * S::nb) return false;
+    if (!S::last || keep < 0) return true;
+    const int j = jj >= S::nb ? jj - S::nb : jj;
+    return j <= keep || j >= S::nb - keep;
+}
+
+// Unpack step of one residue of a transformed pair: thread `tid` of `nthreads` walks the quotients q = tid,
+// tid + nthreads, ... of residue s (its transform in buffer ob, the partner residue's in buffer pb), forms
+// Im F_j and Im F_{M-j} of every needed pair (j <= jn, or the mirror M - j <= jn) and stores
+// u_j = Im F_j * sc / j at u[j-1].  Modes above M/2 are reached as mirrors from the partner residue.
+HMG_HD void pruned_unpack(const cplx* buf, int LP, int R, int M, int s, int ob, int pb, int jn, const UnpackTw* twN,
+                          double sc, double* u, int tid, int nthreads) {
+    const int half = M / 2;
+    const bool hi_any = jn >= M - half;             // does any mirror M - j with j <= M/2 lie within jn at all
+    for (int q = tid + (s == 0 ? 1 : 0);; q += nthreads) {
+        const PrunedPair pr = pruned_pair(R, LP, s, q);
+        if (pr.j > half) break;
+        const bool lo = pr.j <= jn, hi = M - pr.j <= jn;
+        if (!lo && !hi) {
+            if (!hi_any) break;                     // j grows with q: nothing further is needed
+            continue;
+        }
+        const cplx zj = buf[ob * LP + q], zmj = buf[pb * LP + pr.qp];
+        const UnpackTw w = twN[pr.j];
+        double fa, fb;
+        unpack_imag_pair(zj, zmj, w.co, w.si, fa, fb);
+        u[pr.j - 1] = fa * sc * w.rj;
+        if (hi && M - pr.j >= 1) u[M - pr.j - 1] = fb * sc * w.rmj;
+    }
+}
+// Which residues a group g = 0 .. R/2 transforms: g and R - g (one buffer for the self-paired g = 0 and 2g = R),
+// and whether a row that needs the modes j <= jn needs the group at all.
+HMG_HD int pruned_group_partner(int R, int g) { return (g == 0 || 2 * g == R) ? -1 : R - g; }
+HMG_HD bool pruned_group_needed(int R, int M, int g, int jn) {
+    return jn >= g || jn >= M - M / 2;              // the smallest mode of the group is g (R - g > g); mirrors: all groups
+}
+// last-pass pruning of a group's transforms: outputs q <= Q and q >= LP - 1 - Q with Q = jn / R + 1 (keep = Q + 1 in
+// fused_pass's convention), nothing pruned when mirrors are needed or the band is not narrow
+HMG_HD int pruned_keep(int R, int M, int nb_last, int jn) {
+    if (jn >= M - M / 2) return -1;
+    const int keep = jn / R + 2;
+    return 2 * keep + 2 < nb_last ? keep : -1;
 }
 
 }  // namespace hmg

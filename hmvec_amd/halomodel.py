@@ -149,6 +149,7 @@ class HaloModel(Cosmology):
         # HMG_NO_GROUPS=1 issues every stage as its own launch at call time (A/B timing, debugging).
         self._groups = os.environ.get("HMG_NO_GROUPS", "0") != "1" and not self._use_lanes
         self._stages = []
+        self._stage_dims = None
 
         # (name, name2) -> (state version, P1h, P2h): a fused launch yields both terms, so the
         # usual get_power_1halo(a,b) followed by get_power_2halo(a,b) streams the tensors once
@@ -202,6 +203,15 @@ class HaloModel(Cosmology):
     def _bump(self):
         """Any change of profiles / HODs / mass function invalidates cached spectra."""
         self._version = getattr(self, "_version", 0) + 1
+
+    def _release_inputs(self, keys):
+        """Drop cached device inputs.  Stages queued earlier (the constructor queues three) hold raw pointers to
+        them and to pool buffers of the shapes they were built for: the queue is issued before anything is
+        released, with the grid sizes recorded when it was built (_stage_dims)."""
+        if self._stages:
+            self._ctx().flush()
+        for k in keys:
+            self._dcache.pop(k, None)
 
     def _dev(self, key, builder):
         """Host array -> device, uploaded once per key (inputs of the path stay resident)."""
@@ -259,6 +269,8 @@ class HaloModel(Cosmology):
         shape = tuple(int(x) for x in shape)
         b = self._pool.get(key)
         if b is None or b.shape != shape:
+            if b is not None:
+                self._ctx().flush()       # a queued stage may still point at the block being replaced
             b = self._ctx().empty(shape)
             self._pool[key] = b
         return b
@@ -309,11 +321,16 @@ class HaloModel(Cosmology):
         """Queue a launch-only stage.  Anything that reads device state goes through the context, which
         issues the queue first (Context.flush), so deferral is invisible to callers."""
         pend = [st[0] for st in self._stages]
+        # The grid sizes a stage was built for travel with it: the raw pointers inside `part` belong to buffers
+        # of exactly these sizes, whatever self.ms / self.ks are by the time the queue is issued.
+        dims = (self._nz, self._nm if getattr(self, "ms", None) is not None else 0, self._nk, getattr(self, "_nq", 0))
         # same kind twice, a producer queued behind its own consumer (it would overwrite what the consumer
-        # still has to read), or the front of a new pass (it rewrites what every queued stage reads): issue
-        # what is queued first
-        if pend and (kind == "front" or kind in pend or any(kind in self._RUNS_AFTER.get(k, ()) for k in pend)):
+        # still has to read), the front of a new pass (it rewrites what every queued stage reads), or a stage
+        # built for another grid than the queued ones: issue what is queued first
+        if pend and (kind == "front" or kind in pend or any(kind in self._RUNS_AFTER.get(k, ()) for k in pend)
+                     or dims != self._stage_dims):
             self._ctx().flush()
+        self._stage_dims = dims
         self._stages.append((kind, part, keep))
         self._ctx().defer(self)
 
@@ -327,7 +344,7 @@ class HaloModel(Cosmology):
         if not st:
             return False
         ctx = self._ctx()
-        nz, nm, nk, nq = self._nz, self._nm, self._nk, getattr(self, "_nq", 0)
+        nz, nm, nk, nq = self._stage_dims          # the sizes at queue time, not the model's current ones
         ref = lambda k: C.byref(st[k]) if k in st else None      # noqa: E731
         x = os.environ.get("HMG_X", "")          # experiment switches (tuning only)
         if "prep_alone" in x:
@@ -385,9 +402,8 @@ class HaloModel(Cosmology):
         Inputs are uploaded on the first call; later calls only launch kernels."""
         ms = np.asarray(ms, dtype=np.float64)
         if getattr(self, "_ms_key", None) is None or not np.array_equal(ms, self._ms_key):
-            for k in [k for k in self._dcache if k != "zs" and k != "ks" and k != "Pzk"
-                      and not (isinstance(k, tuple) and k[0] == "fftgrid")]:
-                self._dcache.pop(k)
+            self._release_inputs([k for k in self._dcache if k != "zs" and k != "ks" and k != "Pzk"
+                                  and not (isinstance(k, tuple) and k[0] == "fftgrid")])
             self._ms_key = ms.copy()
         self.ms = ms
         self._bump()
@@ -701,6 +717,8 @@ class HaloModel(Cosmology):
         thr = np.ascontiguousarray(log10mstar_thresh, dtype=np.float64)
         cached = self._dcache.get(("thr", key))
         if cached is None or cached[0].shape != thr.shape:
+            if cached is not None:
+                self._release_inputs([("thr", key)])
             cached = (thr.copy(), ctx.upload(thr))
             self._dcache[("thr", key)] = cached
         elif not np.array_equal(cached[0], thr):

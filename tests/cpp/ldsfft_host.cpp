@@ -93,3 +93,77 @@ extern "C" int ldsfft_rfft_imag_spec2500(const double* y, int nz_from, int nthre
     }
     return 0;
 }
+
+// The pruned decomposition of the long-grid route (ldsfft.hpp, "Long radial grids with short support"), sequenced as
+// profile_pruned_kernel sequences it: per group of residues {g, R-g} the twiddled copies of the row, the passes of
+// the compile-time plan of length LP over both buffers (all loads, barrier, all stores), the unpack step.
+// y must be zero from real sample 2 LP on.  Writes Im F_j = u_j * j for the needed modes, NaN elsewhere.
+template <int LP, int PS>
+static void run_sub_passes(std::vector<cplx>& buf, const std::vector<cplx>& twL, int nbuf, int keep, int nthreads) {
+    if constexpr (PS < SubPass<LP, 0>::P.npass) {
+        using S = SubPass<LP, PS>;
+        const int maxb = (2 * S::nb + nthreads - 1) / nthreads;
+        std::vector<cplx> regs((size_t)nthreads * maxb * S::R);
+        for (int tid = 0; tid < nthreads; ++tid)
+            for (int b = 0; b < maxb; ++b) {
+                const int jj = tid + b * nthreads;
+                if (sub_pass_active<LP, PS>(jj, nbuf, keep))
+                    sub_pass_load<LP, PS>(buf.data(), twL.data(), jj, &regs[((size_t)tid * maxb + b) * S::R]);
+            }
+        for (int tid = 0; tid < nthreads; ++tid)
+            for (int b = 0; b < maxb; ++b) {
+                const int jj = tid + b * nthreads;
+                if (sub_pass_active<LP, PS>(jj, nbuf, keep))
+                    sub_pass_store<LP, PS>(buf.data(), jj, &regs[((size_t)tid * maxb + b) * S::R]);
+            }
+        run_sub_passes<LP, PS + 1>(buf, twL, nbuf, keep, nthreads);
+    }
+}
+template <int LP>
+static int pruned_rfft_imag(const double* y, int n, int nthreads, int jn, double* imF) {
+    const int M = n / 2;
+    if (n % 2 || M % LP || M / LP < 2) return 2;
+    const int R = M / LP;
+    for (int i = 2 * LP; i < n; ++i)
+        if (y[i] != 0.0) return 4;
+    const long double twopi = 6.283185307179586476925286766559L;
+    std::vector<cplx> twB(M), twL(LP), src(LP), buf(2 * (size_t)LP, cplx{1.0e30, -1.0e30});
+    std::vector<UnpackTw> twN(M / 2 + 1);
+    for (int t = 0; t < M; ++t) twB[t] = {(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
+    for (int t = 0; t < LP; ++t) twL[t] = {(double)cosl(twopi * t / LP), (double)-sinl(twopi * t / LP)};
+    for (int j = 0; j <= M / 2; ++j)
+        twN[j] = UnpackTw{(double)cosl(twopi * j / n), (double)sinl(twopi * j / n), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
+    for (int p = 0; p < LP; ++p) src[p] = {y[2 * p], y[2 * p + 1]};
+    std::vector<double> u(M, NAN);
+    constexpr int nb_last = SubPass<LP, SubPass<LP, 0>::P.npass - 1>::nb;
+    for (int g = 0; g <= R / 2; ++g) {
+        if (!pruned_group_needed(R, M, g, jn)) continue;
+        const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
+        for (int tid = 0; tid < nthreads; ++tid)
+            for (int p = tid; p < LP; p += nthreads) {
+                buf[p] = cmul(src[p], twB[g * p]);
+                if (nbuf == 2) buf[LP + p] = cmul(src[p], twB[s1 * p]);
+            }
+        run_sub_passes<LP, 0>(buf, twL, nbuf, pruned_keep(R, M, nb_last, jn), nthreads);
+        for (int tid = 0; tid < nthreads; ++tid) {
+            pruned_unpack(buf.data(), LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, twN.data(), 1.0, u.data(), tid, nthreads);
+            if (nbuf == 2) pruned_unpack(buf.data(), LP, R, M, s1, 1, 0, jn, twN.data(), 1.0, u.data(), tid, nthreads);
+        }
+    }
+    imF[0] = 0.0;
+    imF[M] = 0.0;
+    for (int j = 1; j < M; ++j) imF[j] = u[j - 1] * j;
+    return 0;
+}
+extern "C" int ldsfft_pruned_rfft_imag(const double* y, int n, int LP, int nthreads, int jn, double* imF /* n/2+1 */) {
+    switch (LP) {
+        case 1000: return pruned_rfft_imag<1000>(y, n, nthreads, jn, imF);
+        case 1024: return pruned_rfft_imag<1024>(y, n, nthreads, jn, imF);
+        case 1250: return pruned_rfft_imag<1250>(y, n, nthreads, jn, imF);
+        case 1500: return pruned_rfft_imag<1500>(y, n, nthreads, jn, imF);
+        case 2000: return pruned_rfft_imag<2000>(y, n, nthreads, jn, imF);
+        case 2048: return pruned_rfft_imag<2048>(y, n, nthreads, jn, imF);
+        case 2500: return pruned_rfft_imag<2500>(y, n, nthreads, jn, imF);
+        default: return 3;
+    }
+}

@@ -65,7 +65,8 @@ def test_grouped_pass_equals_one_launch_per_stage(monkeypatch, nz, nm, nk, mf):
 @pytest.mark.parametrize("nz,nm", [(3, 64), (20, 100), (2, 96), (8, 128), (17, 513)])
 def test_hod_right_behind_the_constructor_rides_with_the_front(monkeypatch, nz, nm):
     """Constructor + add_hod with nothing read in between: one front launch (contraction | halo stage | HOD
-    occupations) and one rows group whose chain is mass function -> n_gal, b_g sums.  On fresh buffers, so that
+    occupations), one rows group (n, b tiles | NFW rows; hmg_group_rows rejects a mass function and an HOD
+    together) and the n_gal, b_g sums as the per-z chain of hmg_group_profile.  On fresh buffers, so that
     a sum taken from stale memory cannot pass (a repeated pass would hide it: the stale values are the right ones)."""
     import hmvec_amd as hm
     zs = np.linspace(0.01, 2.0, nz)
@@ -176,3 +177,38 @@ def test_group_entry_points_reject_bad_arguments():
     assert b"sums of an HOD" in lib.hmg_last_error()
     assert lib.hmg_group_profile(ctx.handle, 2, 4, 8, None, None, None) != 0
     assert lib.hmg_power_batch_run(ctx.handle, 2, 4, 8, None, 0) != 0
+
+
+@pytest.mark.parametrize("nm_new", [150, 40])
+def test_queue_built_for_one_mass_grid_is_issued_before_the_grid_changes(monkeypatch, nm_new):
+    """the constructor queues front, massfn and nfw with raw pointers into (nz, nm) buffers.
+    init_mass_function(ms2) with another length, and no read in between, must issue that queue with the sizes it
+    was built for BEFORE the inputs are released and the pool buffers replaced - with the model's current nm
+    the stale pass would write nz*nm_new(*nk) elements into nz*nm_old(*nk) allocations."""
+    import hmvec_amd as hm
+    zs = np.array([0.2, 0.9, 1.7])
+    ks = np.geomspace(1e-4, 100, 70)
+    ms1, ms2 = np.geomspace(2e10, 1e17, 64), np.geomspace(1e11, 5e16, nm_new)
+    out = []
+    for grouped in (False, True):
+        monkeypatch.setenv("HMG_NO_GROUPS", "0" if grouped else "1")
+        h = hm.HaloModel(zs, ks, ms=ms1, accuracy="low", engine="analytic")
+        if grouped:
+            assert [s[0] for s in h._stages] == ["front", "massfn", "nfw"] and h._stage_dims[1] == 64
+        h.init_mass_function(ms2)              # nothing was read: the first queue is still pending here
+        if grouped:
+            assert h._stage_dims[1] == nm_new
+        h.add_nfw_profile("nfw", ignore_existing=True)
+        h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000)
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0)
+        st = state(h)
+        assert st["uk_nfw"].shape == (3, nm_new, 70) and st["nzm"].shape == (3, nm_new)
+        st["P"] = h.get_power("g", "electron")
+        out.append(st)
+    assert_same(out[0], out[1])
+    # and a fresh model on the second grid gives the same numbers as the re-initialised one
+    monkeypatch.setenv("HMG_NO_GROUPS", "0")
+    f = build(monkeypatch, True, zs, ms2, ks)
+    ref = state(f)
+    ref["P"] = f.get_power("g", "electron")
+    assert_same(out[1], ref)

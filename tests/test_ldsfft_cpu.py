@@ -21,6 +21,9 @@ def lib(tmp_path_factory):
     lib.ldsfft_rfft_imag.restype = ctypes.c_int
     lib.ldsfft_rfft_imag_spec2500.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.ldsfft_rfft_imag_spec2500.restype = ctypes.c_int
+    lib.ldsfft_pruned_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p]
+    lib.ldsfft_pruned_rfft_imag.restype = ctypes.c_int
     return lib
 
 
@@ -64,3 +67,34 @@ def test_compile_time_plan_sequence_with_truncated_rows(lib, nonzero):
     assert np.max(np.abs(out - ref.imag)) < 4e-15 * scale * np.log2(5000)
     # pruning only drops terms that are exactly zero: the two sequences agree as numbers
     assert np.array_equal(out, gen)
+
+
+@pytest.mark.parametrize("n,LP,nonzero,jn", [
+    (30000, 1000, 1639, 394), (30000, 1000, 2000, 5522), (30000, 1000, 1200, 3), (30000, 1000, 1999, 15000),
+    (30000, 1000, 900, 7499), (30000, 1000, 900, 7500), (30000, 1000, 900, 7501), (30000, 1250, 2500, 800),
+    (30000, 1500, 3000, 53), (30000, 2500, 4100, 2000), (40000, 1250, 2400, 9000), (40000, 2000, 3999, 16000),
+    (40000, 2500, 5000, 20000), (40000, 1000, 1, 0), (10000, 1000, 1366, 1220), (10000, 2500, 683, 2210),
+    (32768, 1024, 2048, 700), (32768, 2048, 4000, 8191), (5000, 1250, 2500, 1249), (6000, 1000, 2000, 33),
+    (8000, 2000, 1, 1999), (4096, 1024, 7, 1024)])
+def test_pruned_decomposition_matches_numpy(lib, n, LP, nonzero, jn):
+    """A row of n real samples that is zero from sample `nonzero` on, transformed as R = n/2/LP pairs of length-LP
+    transforms (the long-grid route of the fused profile kernel): every mode j <= jn - and every mirror M - j <= jn -
+    equals numpy's rfft, for odd and even R, LP, the self-paired residues 0 and R/2, and any jn."""
+    rng = np.random.default_rng(n + LP + nonzero)
+    y = np.zeros(n)
+    y[:nonzero] = rng.standard_normal(nonzero) * np.exp(-np.linspace(0, 3, nonzero))
+    M = n // 2
+    out = np.zeros(M + 1)
+    assert lib.ldsfft_pruned_rfft_imag(y.ctypes.data, n, LP, 512, jn, out.ctypes.data) == 0
+    ref = np.fft.rfft(y)
+    scale = np.max(np.abs(ref))
+    need = np.arange(1, min(jn, M - 1) + 1)
+    assert need.size == 0 or np.max(np.abs(out[need] - ref.imag[need])) < 4e-15 * scale * np.log2(n)
+    assert not np.any(np.isnan(out[need]))
+
+
+def test_pruned_decomposition_rejects_what_it_cannot_take(lib):
+    y = np.ones(30000)
+    out = np.zeros(15001)
+    assert lib.ldsfft_pruned_rfft_imag(y.ctypes.data, 30000, 1000, 512, 100, out.ctypes.data) == 4    # support too long
+    assert lib.ldsfft_pruned_rfft_imag(y.ctypes.data, 30000, 2000, 512, 100, out.ctypes.data) == 2    # LP does not divide M
