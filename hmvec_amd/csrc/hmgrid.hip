@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/hmgrid.h"
@@ -82,6 +83,18 @@ struct FusedPlan {
     int maxb = 0, maxp = 0;
 };
 
+struct PrunedPlan {                       // tables of the pruned long-grid route, per nxs
+    hmg::cplx* twB = nullptr;             // exp(-2 pi i t / M), t < M = nxs/2
+    hmg::UnpackTw* twN = nullptr;         // unpack constants for j <= M/2
+};
+struct SupportKey {
+    const void *cmax, *xs;
+    int rows, nxs;
+    bool operator<(const SupportKey& o) const {
+        return std::tie(cmax, xs, rows, nxs) < std::tie(o.cmax, o.xs, o.rows, o.nxs);
+    }
+};
+
 struct hmg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;             // stream of the current lane
@@ -96,6 +109,12 @@ struct hmg_ctx {
     std::map<int, struct FusedPlan> fused;          // nxs -> workgroup-FFT tables
     size_t fft_chunk_bytes = 0;                    // 0 = default
     int use_fused_fft = 1;                         // HMG_FUSED_FFT=0 forces the rocFFT path
+    int use_pruned_fft = 1;                        // HMG_PRUNED_FFT=0: long grids go to rocFFT as before round 4
+    std::map<int, PrunedPlan> pruned;              // nxs -> tables of the pruned long-grid route
+    std::map<SupportKey, int> support;             // last measured support bound (packed samples) of a launch's rows
+    int* d_fault = nullptr;                        // device word a kernel raises when it cannot do what it was launched for
+    int* h_fault = nullptr;                        // its pinned host twin
+    bool fault_armed = false;                      // a kernel that may raise it ran since the last check
     int sig_nz = 0, sig_nm = 0, sig_nq = 0;        // shape of the partial sums the last sigma^2 contraction left in scratch[4]
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
@@ -136,11 +155,27 @@ static int event_at(hmg_ctx* c, int slot, hipEvent_t* out) {
     return 0;
 }
 
+// A kernel that finds it cannot do what it was launched for (a row whose support exceeds the plan the launch was
+// sized for) raises the context's fault word instead of writing wrong numbers quietly; synchronising calls report it.
+static int check_fault(hmg_ctx* c) {
+    if (!c->fault_armed) return 0;
+    c->fault_armed = false;
+    HIP_TRY(hipMemcpyAsync(c->h_fault, c->d_fault, sizeof(int), hipMemcpyDeviceToHost, c->lanes[0]));
+    HIP_TRY(hipStreamSynchronize(c->lanes[0]));
+    if (*c->h_fault) {
+        *c->h_fault = 0;
+        HIP_TRY(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->lanes[0]));
+        c->support.clear();
+        return fail("device fault", "a profile row's support exceeded the bound its launch was sized for (the rows were "
+                    "filled with NaN); the cached bound is dropped - run the step eagerly again", __FILE__, __LINE__);
+    }
+    return 0;
+}
 static int sync_all(hmg_ctx* c) {
     REQUIRE(!c->capturing, "this call synchronises the device and cannot be part of a captured step");
     for (auto& st : c->lanes) HIP_TRY(hipStreamSynchronize(st));
     c->lanes_dirty = false;
-    return 0;
+    return check_fault(c);
 }
 
 static int ensure_scratch(hmg_ctx* c, int slot, size_t bytes) {
@@ -2916,6 +2951,11 @@ static int ctx_init(hmg_ctx* c, int device) {
         HIP_TRY(hipMemcpy(c->d_sici, &t, sizeof(t), hipMemcpyHostToDevice));
     }
     if (const char* s = getenv("HMG_FUSED_FFT")) c->use_fused_fft = atoi(s);
+    if (const char* s = getenv("HMG_PRUNED_FFT")) c->use_pruned_fft = atoi(s);
+    HIP_TRY(hipMalloc((void**)&c->d_fault, sizeof(int)));
+    HIP_TRY(hipMemset(c->d_fault, 0, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void**)&c->h_fault, sizeof(int), hipHostMallocDefault));
+    *c->h_fault = 0;
     if (const char* s = getenv("HMG_FFT_CHUNK_MB")) c->fft_chunk_bytes = (size_t)atol(s) << 20;
     return 0;
 }
@@ -2955,6 +2995,12 @@ int hmg_ctx_destroy(hmg_ctx* c) {
         if (kv.second.twM) (void)hipFree(kv.second.twM);
         if (kv.second.twN) (void)hipFree(kv.second.twN);
     }
+    for (auto& kv : c->pruned) {
+        if (kv.second.twB) (void)hipFree(kv.second.twB);
+        if (kv.second.twN) (void)hipFree(kv.second.twN);
+    }
+    if (c->d_fault) (void)hipFree(c->d_fault);
+    if (c->h_fault) (void)hipHostFree(c->h_fault);
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     for (auto& kv : c->graph_blocks)
@@ -3108,7 +3154,7 @@ int hmg_memcpy_d2h(hmg_ctx* c, void* h, const void* d, size_t bytes) {
     if (bytes < (256u << 10)) {
         HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        return 0;
+        return check_fault(c);
     }
     if (ensure_pinned(c)) return 1;
     // software pipeline: DMA chunk i+1 into the other buffer while chunk i is copied out
@@ -3130,7 +3176,7 @@ int hmg_memcpy_d2h(hmg_ctx* c, void* h, const void* d, size_t bytes) {
         len[bo] = 0;
         bo ^= 1;
     }
-    return 0;
+    return check_fault(c);
 }
 int hmg_memcpy_d2d(hmg_ctx* c, void* dst, const void* src, size_t bytes) {
     REQUIRE(c && dst && src, "NULL argument");
@@ -3231,6 +3277,7 @@ int hmg_graph_launch(hmg_ctx* c, int id) {
     auto it = c->graphs.find(id);
     REQUIRE(it != c->graphs.end(), "unknown graph id");
     HIP_TRY(hipGraphLaunch(it->second, c->stream));
+    if (!c->pruned.empty()) c->fault_armed = true;    // the graph may hold a launch that can raise the fault word
     return 0;
 }
 int hmg_graph_destroy(hmg_ctx* c, int id) {
@@ -3612,6 +3659,116 @@ static int launch_fused_group(hmg_ctx* c, const FusedArgs& A, int rows, const Ch
     return 0;
 }
 
+
+// ---- pruned long-grid route (profile_pruned_kernel) -------------------------------------------------------
+// Lengths of the sub-transforms that are compiled in.  A launch takes the smallest one that divides M = nxs/2
+// and covers the support bound of its rows.
+static const int PRUNED_LP[] = {1000, 1024, 1250, 1500, 2000, 2048, 2500};
+
+static int get_pruned_plan(hmg_ctx* c, int nxs, PrunedPlan** out) {
+    auto it = c->pruned.find(nxs);
+    if (it != c->pruned.end()) { *out = &it->second; return 0; }
+    const int M = nxs / 2;
+    PrunedPlan P;
+    std::vector<cplx> twB(M);
+    std::vector<UnpackTw> twN(M / 2 + 1);
+    const long double twopi = 6.283185307179586476925286766559L;
+    for (int t = 0; t < M; ++t) twB[t] = cplx{(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
+    for (int j = 0; j <= M / 2; ++j)
+        twN[j] = UnpackTw{(double)cosl(twopi * j / nxs), (double)sinl(twopi * j / nxs), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
+    HIP_TRY(hipMalloc((void**)&P.twB, twB.size() * sizeof(cplx)));
+    HIP_TRY(hipMalloc((void**)&P.twN, twN.size() * sizeof(UnpackTw)));
+    HIP_TRY(hipMemcpy(P.twB, twB.data(), twB.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.twN, twN.data(), twN.size() * sizeof(UnpackTw), hipMemcpyHostToDevice));
+    auto res = c->pruned.emplace(nxs, P);
+    *out = &res.first->second;
+    return 0;
+}
+
+// Support bound of a launch's rows in packed samples.  Eager calls measure it (one small kernel, a 4-byte copy);
+// inside a captured step the value of the last eager call with the same arrays is used - what a replay computes
+// is what was captured - and the kernel itself re-checks every row (fault word).
+static int profile_support(hmg_ctx* c, int rows, int nxs, const double* xs, const double* cmax, int* p0max) {
+    const SupportKey key{cmax, xs, rows, nxs};
+    if (c->capturing) {
+        auto it = c->support.find(key);
+        REQUIRE(it != c->support.end(), "profile support bound unknown inside a captured step: run the step once eagerly first");
+        *p0max = it->second;
+        return 0;
+    }
+    if (ensure_scratch(c, 2, 64)) return 1;
+    int* d_p0 = (int*)c->scratch[2];
+    HIP_TRY(hipMemsetAsync(d_p0, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(profile_support_kernel, grid1d((size_t)rows, 256), dim3(256), 0, c->stream, rows, nxs, xs, cmax, d_p0);
+    HIP_TRY(hipGetLastError());
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, d_p0, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->support[key] = h;
+    *p0max = h;
+    return 0;
+}
+
+template <int LP>
+static int launch_pruned(hmg_ctx* c, PrunedArgs G, int rows, size_t rows_per_launch) {
+    const size_t lds = (size_t)3 * LP * 16 + 32 * sizeof(double);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)profile_pruned_kernel<FUSED_NT, LP>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int r0 = 0; r0 < rows; r0 += (int)rows_per_launch) {
+        const int nr = rows - r0 < (int)rows_per_launch ? rows - r0 : (int)rows_per_launch;
+        G.row0 = r0;
+        hipLaunchKernelGGL((profile_pruned_kernel<FUSED_NT, LP>), dim3(nr), dim3(FUSED_NT), lds, c->stream, G);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// Returns 0 and *taken = 1 when the pruned route ran, *taken = 0 when the launch is not one it can take.
+static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* taken) {
+    *taken = 0;
+    const int nxs = A0.nxs, M = nxs / 2;
+    if ((nxs & 1) || M < 2 * PRUNED_LP[0]) return 0;
+    bool any = false;
+    for (int lp : PRUNED_LP) any = any || (M % lp == 0 && M / lp >= 2);
+    if (!any) return 0;
+    int p0max = 0;
+    if (profile_support(c, rows, nxs, A0.xs, A0.cmax, &p0max)) return 1;
+    int LP = 0;
+    for (int lp : PRUNED_LP)
+        if (M % lp == 0 && M / lp >= 2 && lp >= p0max) { LP = lp; break; }
+    if (!LP) return 0;                                   // support too long (e.g. tSZ pressure at xmax = 2): rocFFT
+    PrunedPlan* PP = nullptr;
+    FusedPlan* FL = nullptr;
+    if (get_pruned_plan(c, nxs, &PP)) return 1;
+    if (get_fused_plan(c, 2 * LP, &FL)) return 1;
+    REQUIRE(FL != nullptr, "no twiddle table for the sub-transform length");
+    // scratch line of M doubles per row, at most 8 GiB per launch
+    size_t rpl = ((size_t)8 << 30) / ((size_t)M * 8);
+    if (rpl < 1) rpl = 1;
+    if (rpl > (size_t)rows) rpl = rows;
+    if (ensure_scratch(c, 0, rpl * (size_t)M * 8)) return 1;
+    PrunedArgs G;
+    G.F = A0;
+    G.F.twN = PP->twN;
+    G.M = M; G.R = M / LP; G.twB = PP->twB; G.twL = FL->twM; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
+    int rc = 1, stop = -1;
+    if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
+    switch (LP) {
+        case 1000: rc = launch_pruned<1000>(c, G, rows, rpl); break;
+        case 1024: rc = launch_pruned<1024>(c, G, rows, rpl); break;
+        case 1250: rc = launch_pruned<1250>(c, G, rows, rpl); break;
+        case 1500: rc = launch_pruned<1500>(c, G, rows, rpl); break;
+        case 2000: rc = launch_pruned<2000>(c, G, rows, rpl); break;
+        case 2048: rc = launch_pruned<2048>(c, G, rows, rpl); break;
+        case 2500: rc = launch_pruned<2500>(c, G, rows, rpl); break;
+    }
+    if (rc) return 1;
+    c->fault_armed = true;
+    *taken = 1;
+    return bracket_close(c, stop);
+}
+
 // One hmg_profile_fft; with a chain (nchain > 0) and a length the in-LDS transform takes, chain and rows share
 // the launch, otherwise *chain_done stays 0 and the caller issues the chain on its own.
 static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part& p, const ChainArgs* C,
@@ -3637,6 +3794,20 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
     if (c->use_fused_fft && xs_aligned) {
         FusedPlan* FP = nullptr;
         if (get_fused_plan(c, nxs, &FP)) return 1;
+        if (!FP && c->use_pruned_fft) {
+            // a grid too long for one LDS row: the pruned decomposition, if the support of the rows is short enough
+            FusedArgs A{};
+            A.nxs = nxs; A.nm = nm; A.nk = nk; A.do_norm = do_mass_norm;
+            A.xs = xs; A.twM = nullptr; A.twN = nullptr; A.kts = kts;
+            A.amp = amp; A.xc = xcs; A.alpha = alpha; A.expo = expo;
+            A.amp_c = amp_c; A.xc_c = xc_c; A.alpha_c = alpha_c; A.expo_c = expo_c; A.gamma = gamma;
+            A.step = step; A.cmax = cmax; A.rss = rss; A.zs = zs; A.ks = ks; A.post = post; A.out = out;
+            A.nconst = nconst; A.cconst = cconst;
+            A.logx = logxs;
+            int taken = 0;
+            if (profile_fft_pruned(c, A, rows, &taken)) return 1;
+            if (taken) return 0;
+        }
         if (FP) {
             FusedArgs A;
             A.plan = FP->plan; A.nxs = nxs; A.nm = nm; A.nk = nk; A.do_norm = do_mass_norm;

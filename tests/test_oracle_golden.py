@@ -172,3 +172,28 @@ def test_second_tracers_and_tsz_projections(alpha_table):
     one = np.ones(zs.size)
     assert rel_err(hmref.limber_integral(g["ells"], zs, ks, Pyy, zs, one, one, hz, chis), g["C_yy"]) < 1e-12
     assert rel_err(hmref.limber_integral(g["ells"], zs, ks, Pym, zs, W, one, hz, chis), g["C_ky"]) < 1e-12
+
+
+def test_long_radial_grids_case_f():
+    """case_f: the reference run with the radial grids its own callers use (nxs = 30000 / xmax = 50 gas,
+    nxs = 40000 / xmax = 200 numeric NFW, nxs = 30000 / xmax = 2 pressure) pins the oracle at those lengths."""
+    g = load_golden("case_f")
+    p = merged_params()
+    ci = cosmo_inputs_from_golden(g, p)
+    om = hmref.RefHaloModel(ci, g["zs"], g["ks"], g["ms"], p)
+    om.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], 30000, 50)
+    assert np.max(np.abs(om.uk_profiles["electron"] - g["uk_electron"])) < 1e-13
+    _, u = om.add_nfw_profile("nfwnum", numeric=True)
+    assert np.max(np.abs(u - g["uk_nfwnum"])) < 1e-13
+    sigT = sc.physical_constants["Thomson cross section"][0]
+    me = sc.physical_constants["electron mass"][0] / p["mSun"]
+    om.add_battaglia_pres_profile("y", p["battaglia_pres_alpha"], p["battaglia_pres_gamma"],
+                                  battaglia_defaults["pres"], 30000, 2, sigT, me, sc.c)
+    assert rel_err(om.pk_profiles["y"], g["pk_y"]) < 1e-10
+    om.add_hod("g", mthresh=10 ** 10.5 + g["zs"] * 0.0, satellite_profile_name="nfwnum")
+    for a, b in (("electron", "electron"), ("nfw", "electron"), ("nfwnum", "nfwnum"), ("g", "electron"), ("y", "y"),
+                 ("nfw", "y")):
+        ok, w = power_close(om.get_power_1halo(a, b), g[f"P1h_{a}_{b}"])
+        assert ok, (a, b, w)
+        ok, w = power_close(om.get_power_2halo(a, b), g[f"P2h_{a}_{b}"])
+        assert ok, (a, b, w)

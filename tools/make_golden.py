@@ -401,6 +401,37 @@ def run_case_e(hm):
     return out
 
 
+def run_case_f(hm):
+    """The radial grids the reference's own callers use (too long for one LDS row: the pruned long-grid route):
+    add_battaglia_profile(xmax=50, nxs=30000) as in examples/lensing_baryons.py:27 and bin/tests.py:308, the numeric
+    NFW branch at its defaults nxs=40000 / xmax=200 (hmvec/params.py:59-60), and the tSZ notebook's
+    add_battaglia_pres_profile(xmax=2, nxs=30000) (support not short: the rocFFT route).  Tiny (z, m) grid."""
+    zs = np.array([0.3, 1.1, 2.4])
+    ms = np.geomspace(2e10, 1e17, 10)
+    ks = np.geomspace(1e-4, 100, 60)
+    out = dict(zs=zs, ks=ks, ms=ms)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low")
+    for k, v in cosmo_inputs(h, zs).items():
+        out["in_" + k] = np.asarray(v)
+    out["cs"] = h.concentration()
+    out["uk_nfw"] = h.uk_profiles["nfw"]
+    h.add_battaglia_profile("electron", family="AGN", xmax=50, nxs=30000)
+    out["uk_electron"] = h.uk_profiles["electron"]
+    _, u = h.add_nfw_profile("nfwnum", numeric=True)
+    out["uk_nfwnum"] = u
+    h.add_battaglia_pres_profile("y", xmax=2, nxs=30000)
+    out["pk_y"] = h.pk_profiles["y"]
+    h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, satellite_profile_name="nfwnum")
+    for a, b in (("electron", "electron"), ("nfw", "electron"), ("nfwnum", "nfwnum"), ("g", "electron"), ("y", "y"),
+                 ("nfw", "y")):
+        out[f"P1h_{a}_{b}"] = h.get_power_1halo(a, b)
+        out[f"P2h_{a}_{b}"] = h.get_power_2halo(a, b)
+    out["meta_json"] = np.array(json.dumps(dict(
+        electron=dict(family="AGN", xmax=50, nxs=30000), nfwnum=dict(nxs=40000, xmax=200),
+        y=dict(xmax=2, nxs=30000), hod=dict(mthresh="10**10.5", satellite="nfwnum"))))
+    return out
+
+
 def run_extra_pins(hm):
     """Helpers off the grid path that the reference exports and its own scripts use: Cosmology.sigma_crit
     (hmvec/hmvec.py:595), Cosmology.bias_fnl (examples/fnl.py) and fft.uk_brute_force (bin/tests.py:36)."""
@@ -483,6 +514,9 @@ def main():
     # E: accuracy='medium' / 'high' on a tabulated, non-separable P(k,z) (row N3's host seam)
     if want("case_e"):
         save("case_e", run_case_e(hm))
+    # F: the long radial grids of the reference's own callers (nxs = 30000 / 40000)
+    if want("case_f"):
+        save("case_f", run_case_f(hm))
     if want("extra_pins"):
         save("extra_pins", run_extra_pins(hm))
     if not args.skip_readme:
