@@ -110,6 +110,7 @@ struct hmg_ctx {
     size_t fft_chunk_bytes = 0;                    // 0 = default
     int use_fused_fft = 1;                         // HMG_FUSED_FFT=0 forces the rocFFT path
     int use_pruned_fft = 1;                        // HMG_PRUNED_FFT=0: long grids go to rocFFT as before round 4
+    int pruned_lp_min = 0;                         // HMG_PRUNED_LP_MIN: smallest sub-transform length to consider
     std::map<int, PrunedPlan> pruned;              // nxs -> tables of the pruned long-grid route
     std::map<SupportKey, int> support;             // last measured support bound (packed samples) of a launch's rows
     int* d_fault = nullptr;                        // device word a kernel raises when it cannot do what it was launched for
@@ -1442,8 +1443,15 @@ struct PrunedArgs {
     int row0;             // first row of this launch
 };
 
+// The passes 1 .. npass-1 of the sub-transforms (pass 0 runs from registers, profile_pruned_row).
+// (Measured and dropped, MI355X: a thread works on the same butterflies in every group of residues, so its twiddle
+// per pass can be fetched once per row and held in registers - 16 more VGPRs at LP = 1000 spill inside the group loop
+// under the 64- and the 80-register caps alike: 1.16 -> 2.38 / 2.04 ms.)
+#ifndef HMG_PRUNED_TWLDS
+#define HMG_PRUNED_TWLDS 0
+#endif
 template <int NT, int LP, int PS>
-__device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* __restrict__ twL, int nbuf, int keep) {
+__device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* twL, int nbuf, int keep) {
     if constexpr (PS < SubPass<LP, 0>::P.npass) {
         using S = SubPass<LP, PS>;
         constexpr int MAXB = (2 * S::nb + NT - 1) / NT;
@@ -1467,13 +1475,25 @@ __device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* __restrict_
 template <int NT, int LP>
 __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row, double* smem) {
     const FusedArgs& A = G.F;
-    // dynamic LDS: [0, LP) cplx = the packed samples of the row, [LP, 3 LP) = the two transform buffers, then 32
-    // doubles of scalars laid out as in profile_fused_row
-    cplx* src = reinterpret_cast<cplx*>(smem);
-    cplx* buf = src + LP;
-    double* red = smem + 6 * (size_t)LP;
+    // dynamic LDS: [0, 2 LP) cplx = the two transform buffers, then 32 doubles of scalars laid out as in
+    // profile_fused_row.  The packed samples of the row stay in REGISTERS: thread j < LP/R0 owns the R0 inputs
+    // j + t LP/R0 of butterfly j of the first pass (radix R0, sub-transform size 1: no pass twiddles), so the
+    // multiplication by W_M^{rp} and the first pass of every residue's transform need no LDS read at all.
+    cplx* buf = reinterpret_cast<cplx*>(smem);
+    double* red = smem + 4 * (size_t)LP;
     int* s_cnt = reinterpret_cast<int*>(red + 17);
     int* s_jn = reinterpret_cast<int*>(red + 18);
+#if HMG_PRUNED_TWLDS
+    // the twiddle table of the sub-transforms in LDS behind the scalars: the passes of the group loop then make no
+    // global access at all (one ds_read_b128 per butterfly instead of an L2 round trip per pass)
+    cplx* twl = reinterpret_cast<cplx*>(red + 32);
+    for (int t = threadIdx.x; t < LP; t += NT) twl[t] = G.twL[t];
+#else
+    const cplx* __restrict__ twl = G.twL;
+#endif
+    using S0 = SubPass<LP, 0>;
+    constexpr int R0 = S0::R, nb0 = S0::nb, MAXB0 = (nb0 + NT - 1) / NT;
+    static_assert(S0::Ns == 1, "first pass");
     const int M = G.M, R = G.R, nxs = 2 * M;
     const double Aamp = A.amp ? A.amp[row] : A.amp_c;
     const double XC = A.xc ? A.xc[row] : A.xc_c;
@@ -1526,18 +1546,27 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
             red[23] = 1.0 / A.kts[1];
         }
     }
-    // ---- phase A: the LP packed samples that can be non-zero, and the mass norm
+    // ---- phase A: the LP packed samples that can be non-zero (into registers), and the mass norm
+    cplx zp[MAXB0][R0];
     double acc = 0.0;
-    for (int p = threadIdx.x; p < LP; p += NT) {
-        const int j = 2 * p;
-        const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
-        double r0 = 0.0, r1 = 0.0;
-        if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
-        if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
-        src[p] = cplx{xv.x * r0, xv.y * r1};
-        if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
-            const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
-            acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
+#pragma unroll
+    for (int b = 0; b < MAXB0; ++b) {
+#pragma unroll
+        for (int t = 0; t < R0; ++t) {
+            const int jb = threadIdx.x + b * NT;
+            zp[b][t] = cplx{0.0, 0.0};
+            if (jb < nb0) {
+                const int j = 2 * (jb + t * nb0);
+                const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
+                double r0 = 0.0, r1 = 0.0;
+                if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
+                if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+                zp[b][t] = cplx{xv.x * r0, xv.y * r1};
+                if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
+                    const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
+                    acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
+                }
+            }
         }
     }
     {
@@ -1553,20 +1582,34 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
     }
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
-    // ---- phase B + C: per group of residues {g, R - g}: twiddled copies, transforms, unpack into the scratch line
+    // ---- phase B + C: per group of residues {g, R - g}: first pass from registers, the other passes in LDS,
+    // unpack into the scratch line
     double* __restrict__ u = G.u + (size_t)(row - G.row0) * M;
-    constexpr int nb_last = SubPass<LP, SubPass<LP, 0>::P.npass - 1>::nb;
+    constexpr int nb_last = SubPass<LP, S0::P.npass - 1>::nb;
     const int keep = pruned_keep(R, M, nb_last, jn);
     for (int g = 0; g <= R / 2; ++g) {
         if (!pruned_group_needed(R, M, g, jn)) break;          // (groups are needed in ascending order of g)
         const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
-        for (int p = threadIdx.x; p < LP; p += NT) {
-            const cplx zp = src[p];
-            buf[p] = cmul(zp, G.twB[g * p]);
-            if (nbuf == 2) buf[LP + p] = cmul(zp, G.twB[s1 * p]);
+#pragma unroll
+        for (int b = 0; b < MAXB0; ++b) {
+            const int jb = threadIdx.x + b * NT;
+            if (jb < nb0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h < nbuf) {
+                        const int sres = h ? s1 : g;
+                        cplx v[R0];
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) v[t] = cmul(zp[b][t], G.twB[sres * (jb + t * nb0)]);
+                        dft_small<R0>(v);
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) buf[h * LP + jb * R0 + t] = v[t];      // Ns = 1: q = j, k = 0
+                    }
+                }
+            }
         }
         __syncthreads();                                       // (also publishes red[24] before the first unpack)
-        pruned_passes<NT, LP, 0>(buf, G.twL, nbuf, keep);
+        pruned_passes<NT, LP, 1>(buf, twl, nbuf, keep);
         const double sc = red[24];
         pruned_unpack(buf, LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
         if (nbuf == 2) pruned_unpack(buf, LP, R, M, s1, 1, 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
@@ -1619,7 +1662,15 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         A.cconst[row] = u1 * pf;
     }
 }
-template <int LP> constexpr int pruned_occ() { return 3 * LP * 16 + 256 <= 160 * 1024 / 3 ? 6 : (3 * LP * 16 + 256 <= 80 * 1024 ? 4 : 2); }
+#ifndef HMG_PRUNED_OCC
+#define HMG_PRUNED_OCC 0
+#endif
+// waves per SIMD the LDS footprint (two buffers of LP complex numbers [+ the twiddle table]) allows a 512-thread
+// workgroup: 2 per workgroup
+template <int LP> constexpr int pruned_occ() {
+    constexpr int wgs = (160 * 1024) / ((2 + HMG_PRUNED_TWLDS) * LP * 16 + 256);
+    return HMG_PRUNED_OCC ? HMG_PRUNED_OCC : (wgs >= 4 ? 8 : 2 * wgs);
+}
 template <int NT, int LP>
 __global__ __launch_bounds__(NT, pruned_occ<LP>()) void profile_pruned_kernel(PrunedArgs G) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -2952,6 +3003,7 @@ static int ctx_init(hmg_ctx* c, int device) {
     }
     if (const char* s = getenv("HMG_FUSED_FFT")) c->use_fused_fft = atoi(s);
     if (const char* s = getenv("HMG_PRUNED_FFT")) c->use_pruned_fft = atoi(s);
+    if (const char* s = getenv("HMG_PRUNED_LP_MIN")) c->pruned_lp_min = atoi(s);
     HIP_TRY(hipMalloc((void**)&c->d_fault, sizeof(int)));
     HIP_TRY(hipMemset(c->d_fault, 0, sizeof(int)));
     HIP_TRY(hipHostMalloc((void**)&c->h_fault, sizeof(int), hipHostMallocDefault));
@@ -3711,7 +3763,7 @@ static int profile_support(hmg_ctx* c, int rows, int nxs, const double* xs, cons
 
 template <int LP>
 static int launch_pruned(hmg_ctx* c, PrunedArgs G, int rows, size_t rows_per_launch) {
-    const size_t lds = (size_t)3 * LP * 16 + 32 * sizeof(double);
+    const size_t lds = (size_t)(2 + HMG_PRUNED_TWLDS) * LP * 16 + 32 * sizeof(double);
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)profile_pruned_kernel<FUSED_NT, LP>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3735,8 +3787,12 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
     int p0max = 0;
     if (profile_support(c, rows, nxs, A0.xs, A0.cmax, &p0max)) return 1;
     int LP = 0;
+    const int lp_min = c->pruned_lp_min > p0max ? c->pruned_lp_min : p0max;     // (HMG_PRUNED_LP_MIN: tuning / tests)
     for (int lp : PRUNED_LP)
-        if (M % lp == 0 && M / lp >= 2 && lp >= p0max) { LP = lp; break; }
+        if (M % lp == 0 && M / lp >= 2 && lp >= lp_min) { LP = lp; break; }
+    if (!LP)
+        for (int lp : PRUNED_LP)
+            if (M % lp == 0 && M / lp >= 2 && lp >= p0max) { LP = lp; break; }
     if (!LP) return 0;                                   // support too long (e.g. tSZ pressure at xmax = 2): rocFFT
     PrunedPlan* PP = nullptr;
     FusedPlan* FL = nullptr;

@@ -206,6 +206,24 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twste
         if (t + 1 < NIN) w = cmul(w, w1);
     }
 }
+// pass_load with the butterfly's twiddle w1 = W^(k M/(Ns R)) supplied by the caller (a kernel that runs the same pass
+// on many transforms keeps it in a register instead of fetching it from the table every time)
+template <int R, bool SMALL = false>
+HMG_HD void pass_load_w(const cplx* buf, int M, int j, cplx w1, cplx* v) {
+    const int stride = M / R;
+    v[0] = buf[j];
+    cplx w = w1;
+#pragma unroll
+    for (int t = 1; t < R; ++t) {
+        v[t] = cmul(buf[j + t * stride], w);
+        if (t + 1 < R) w = cmul(w, w1);
+    }
+}
+template <int R, bool SMALL = false>
+HMG_HD int pass_twiddle_index(int Ns, int twstep, unsigned magic, int j) {
+    const int k = j - mul_idx<SMALL>((int)div_ns<SMALL>((unsigned)j, magic), Ns);      // j mod Ns
+    return mul_idx<SMALL>(k, twstep);
+}
 template <int R, bool SMALL = false, int NIN = R>
 HMG_HD void pass_store(cplx* buf, int Ns, unsigned magic, int j, cplx* v) {
     static_assert(NIN == R || (R == 5 && NIN == 3), "only the 3-of-5 butterfly exists");
@@ -265,6 +283,19 @@ HMG_HD void sub_pass_load(const cplx* buf, const cplx* twL, int jj, cplx* v) {
     using S = SubPass<LP, PS>;
     const int b = jj >= S::nb ? 1 : 0, j = jj - b * S::nb;
     pass_load<S::R, S::SMALL>(buf + b * LP, twL, LP, S::Ns, S::tws, S::mg, j, v);
+}
+// the same with the twiddle held by the caller: sub_pass_twiddle once, sub_pass_load_w per transform
+template <int LP, int PS>
+HMG_HD cplx sub_pass_twiddle(const cplx* twL, int jj) {
+    using S = SubPass<LP, PS>;
+    const int j = jj >= S::nb ? jj - S::nb : jj;
+    return twL[pass_twiddle_index<S::R, S::SMALL>(S::Ns, S::tws, S::mg, j)];
+}
+template <int LP, int PS>
+HMG_HD void sub_pass_load_w(const cplx* buf, int jj, cplx w1, cplx* v) {
+    using S = SubPass<LP, PS>;
+    const int b = jj >= S::nb ? 1 : 0, j = jj - b * S::nb;
+    pass_load_w<S::R, S::SMALL>(buf + b * LP, LP, j, w1, v);
 }
 template <int LP, int PS>
 HMG_HD void sub_pass_store(cplx* buf, int jj, cplx* v) {

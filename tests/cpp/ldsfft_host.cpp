@@ -139,12 +139,20 @@ static int pruned_rfft_imag(const double* y, int n, int nthreads, int jn, double
     for (int g = 0; g <= R / 2; ++g) {
         if (!pruned_group_needed(R, M, g, jn)) continue;
         const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
-        for (int tid = 0; tid < nthreads; ++tid)
-            for (int p = tid; p < LP; p += nthreads) {
-                buf[p] = cmul(src[p], twB[g * p]);
-                if (nbuf == 2) buf[LP + p] = cmul(src[p], twB[s1 * p]);
-            }
-        run_sub_passes<LP, 0>(buf, twL, nbuf, pruned_keep(R, M, nb_last, jn), nthreads);
+        // first pass (radix R0, sub-transform size 1) straight from the samples a thread owns: j + t LP/R0
+        {
+            using S0 = SubPass<LP, 0>;
+            for (int tid = 0; tid < nthreads; ++tid)
+                for (int jb = tid; jb < S0::nb; jb += nthreads)
+                    for (int hb = 0; hb < nbuf; ++hb) {
+                        const int sres = hb ? s1 : g;
+                        cplx v[S0::R];
+                        for (int t = 0; t < S0::R; ++t) v[t] = cmul(src[jb + t * S0::nb], twB[sres * (jb + t * S0::nb)]);
+                        dft_small<S0::R>(v);
+                        for (int t = 0; t < S0::R; ++t) buf[hb * LP + jb * S0::R + t] = v[t];
+                    }
+        }
+        run_sub_passes<LP, 1>(buf, twL, nbuf, pruned_keep(R, M, nb_last, jn), nthreads);
         for (int tid = 0; tid < nthreads; ++tid) {
             pruned_unpack(buf.data(), LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, twN.data(), 1.0, u.data(), tid, nthreads);
             if (nbuf == 2) pruned_unpack(buf.data(), LP, R, M, s1, 1, 0, jn, twN.data(), 1.0, u.data(), tid, nthreads);
