@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -179,6 +179,8 @@ SIGNATURES = {
     "hmg_comm_allgather": [_P, _P, _P, _Z],
     "hmg_comm_allgather_multi": [_P, _I, C.POINTER(_P), C.POINTER(_P), _Z],
     "hmg_comm_gather_async": [_P, _I, C.POINTER(_P), C.POINTER(_P), _Z, _I, _I, _I],
+    "hmg_comm_allgatherv_multi": [_P, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_Z)],
+    "hmg_comm_gatherv_async": [_P, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_Z), _I, _I, _I],
     "hmg_comm_info": [_P, C.POINTER(_I), C.POINTER(_I)],
     "hmg_comm_barrier": [_P],
     "hmg_comm_destroy": [_P],

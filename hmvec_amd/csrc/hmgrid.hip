@@ -4648,12 +4648,43 @@ int hmg_comm_allgather_multi(hmg_ctx* c, int n, const double* const* send, doubl
     NCCL_TRY(ncclGroupEnd());
     return 0;
 }
+// Slabs of unequal length (nz not a multiple of the number of ranks, e.g. the README grid's nz = 20 on 8 GPUs):
+// rank r contributes h_counts[r] doubles per array, landing at the prefix-sum offset - one ncclBroadcast per
+// (array, rank), all in ONE group launch, so that every slab still arrives in its final position with no
+// padding and no compaction pass.  Equal counts take the all-gather.
+static int comm_gatherv_multi(hmg_ctx* c, int n, const double* const* send, double* const* recv, const size_t* counts) {
+    const int nr = c->comm ? c->comm_size : 1, me = c->comm ? c->comm_rank : 0;
+    bool equal = true;
+    for (int r = 1; r < nr; ++r) equal = equal && counts[r] == counts[0];
+    if (equal) return hmg_comm_allgather_multi(c, n, send, recv, counts[0]);
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        size_t off = 0;
+        for (int r = 0; r < nr; ++r) {
+            if (counts[r]) {
+                ncclResult_t e = ncclBroadcast(r == me ? send[i] : recv[i] + off, recv[i] + off, counts[r], ncclDouble, r,
+                                               c->comm, c->stream);
+                if (e != ncclSuccess) {
+                    ncclGroupEnd();
+                    return fail("ncclBroadcast", ncclGetErrorString(e), __FILE__, __LINE__);
+                }
+            }
+            off += counts[r];
+        }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+}
+int hmg_comm_allgatherv_multi(hmg_ctx* c, int n, const double* const* send, double* const* recv, const size_t* counts) {
+    REQUIRE(c && send && recv && counts && n >= 0, "bad argument");
+    return comm_gatherv_multi(c, n, send, recv, counts);
+}
 // The z-slab gather of one pass, off the compute stream: an event marks "spectra ready" on the
 // current lane, the communication lane waits for it, issues the grouped all-gather and records
 // done_slot.  The next pass calls hmg_event_wait(done_slot) before it overwrites the local spectra,
 // so the collective overlaps the next pass's first kernels instead of extending the step.
-int hmg_comm_gather_async(hmg_ctx* c, int n, const double* const* send, double* const* recv, size_t count,
-                          int ready_slot, int done_slot, int comm_lane) {
+static int comm_gather_async(hmg_ctx* c, int n, const double* const* send, double* const* recv, size_t count,
+                             const size_t* counts, int ready_slot, int done_slot, int comm_lane) {
     REQUIRE(c && send && recv && n >= 0, "bad argument");
     REQUIRE(!c->capturing, "the gather is issued outside captured steps");
     REQUIRE(ready_slot >= 0 && ready_slot < HMG_EVENT_SLOTS && done_slot >= 0 && done_slot < HMG_EVENT_SLOTS, "bad event slot");
@@ -4665,7 +4696,7 @@ int hmg_comm_gather_async(hmg_ctx* c, int n, const double* const* send, double* 
     c->stream = c->lanes[comm_lane];
     c->lanes_dirty = true;
     HIP_TRY(hipStreamWaitEvent(c->stream, ready, 0));
-    const int rc = hmg_comm_allgather_multi(c, n, send, recv, count);
+    const int rc = counts ? comm_gatherv_multi(c, n, send, recv, counts) : hmg_comm_allgather_multi(c, n, send, recv, count);
     if (!rc) {
         hipError_t e = hipEventRecord(done, c->stream);
         c->stream = keep;
@@ -4673,6 +4704,15 @@ int hmg_comm_gather_async(hmg_ctx* c, int n, const double* const* send, double* 
     }
     c->stream = keep;
     return rc;
+}
+int hmg_comm_gather_async(hmg_ctx* c, int n, const double* const* send, double* const* recv, size_t count,
+                          int ready_slot, int done_slot, int comm_lane) {
+    return comm_gather_async(c, n, send, recv, count, nullptr, ready_slot, done_slot, comm_lane);
+}
+int hmg_comm_gatherv_async(hmg_ctx* c, int n, const double* const* send, double* const* recv, const size_t* counts,
+                           int ready_slot, int done_slot, int comm_lane) {
+    REQUIRE(counts, "NULL counts");
+    return comm_gather_async(c, n, send, recv, 0, counts, ready_slot, done_slot, comm_lane);
 }
 int hmg_comm_info(hmg_ctx* c, int* rank, int* nranks) {
     REQUIRE(c && rank && nranks, "NULL argument");

@@ -20,12 +20,21 @@ from . import _native as nat
 
 
 def slab_bounds(nz, world, rank):
-    """Contiguous z-slab [lo, hi) of `rank`; requires nz % world == 0 so that a plain
-    all-gather (equal counts) reassembles the full grid."""
-    if nz % world != 0:
-        raise ValueError(f"nz={nz} must be divisible by the number of ranks ({world})")
-    per = nz // world
-    return rank * per, (rank + 1) * per
+    """Contiguous z-slab [lo, hi) of `rank`.  nz need not be a multiple of the number of ranks (the README grid
+    has nz = 20, /root/reference/README.rst:55): the first nz % world ranks take one redshift more, and the gather
+    moves per-rank counts (slab_counts).  Every rank must own at least one redshift."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside 0..{world - 1}")
+    if nz < world:
+        raise ValueError(f"nz={nz} redshifts cannot be split over {world} ranks (a rank would own none)")
+    base, rem = divmod(nz, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def slab_counts(nz, world):
+    """Redshifts per rank, in rank order (sums to nz)."""
+    return [hi - lo for lo, hi in (slab_bounds(nz, world, r) for r in range(world))]
 
 
 def rendezvous_path(tag, world):
@@ -111,19 +120,36 @@ class RcclComm:
             ctx.call("hmg_comm_init", uid, rank, world)
             self._path = rendezvous_path(tag, world)
 
-    def allgather_rows(self, sends, recvs):
-        """sends[i]: DeviceArray (nz_local, nk) -> recvs[i]: DeviceArray (nz, nk); one group launch."""
+    def _counts(self, counts):
+        """Per-rank element counts as a size_t array, or None when all ranks send the same amount."""
+        if counts is None or len(set(counts)) <= 1:
+            return None
+        if len(counts) != self.world:
+            raise ValueError("one count per rank")
+        return (C.c_size_t * self.world)(*[int(c) for c in counts])
+
+    def allgather_rows(self, sends, recvs, counts=None):
+        """sends[i]: DeviceArray (nz_local, nk) -> recvs[i]: DeviceArray (nz, nk); one group launch.
+        counts: elements per rank when the slabs are unequal (same list on every rank)."""
         n = len(sends)
         sp = (C.c_void_p * n)(*[s.ptr for s in sends])
         rp = (C.c_void_p * n)(*[r.ptr for r in recvs])
-        self.ctx.call("hmg_comm_allgather_multi", n, sp, rp, sends[0].size)
+        cv = self._counts(counts)
+        if cv is None:
+            self.ctx.call("hmg_comm_allgather_multi", n, sp, rp, sends[0].size)
+        else:
+            self.ctx.call("hmg_comm_allgatherv_multi", n, sp, rp, cv)
 
-    def gather_rows_async(self, sends, recvs, ready_slot, done_slot, comm_lane):
+    def gather_rows_async(self, sends, recvs, ready_slot, done_slot, comm_lane, counts=None):
         """allgather_rows on the communication lane, ordered by events (one native call)."""
         n = len(sends)
         sp = (C.c_void_p * n)(*[s.ptr for s in sends])
         rp = (C.c_void_p * n)(*[r.ptr for r in recvs])
-        self.ctx.call("hmg_comm_gather_async", n, sp, rp, sends[0].size, ready_slot, done_slot, comm_lane)
+        cv = self._counts(counts)
+        if cv is None:
+            self.ctx.call("hmg_comm_gather_async", n, sp, rp, sends[0].size, ready_slot, done_slot, comm_lane)
+        else:
+            self.ctx.call("hmg_comm_gatherv_async", n, sp, rp, cv, ready_slot, done_slot, comm_lane)
 
     def allgather_host(self, values):
         """Small host-side all-gather of a float vector (timings); blocks."""
@@ -172,8 +198,11 @@ class ShardedSpectra:
         self._gather = comm.world > 1 or force_gather
         ctx = model._ctx()
         nzl, nk = model.zs.size, model.ks.size
-        if nzl * comm.world != nz_total:
-            raise ValueError("slab size x ranks != nz_total")
+        lo, hi = slab_bounds(nz_total, comm.world, comm.rank)
+        if nzl != hi - lo:
+            raise ValueError(f"rank {comm.rank} of {comm.world} owns {hi - lo} of {nz_total} redshifts, its model has {nzl}")
+        zc = slab_counts(nz_total, comm.world)
+        self.counts = [c * nk for c in zc] if len(set(zc)) > 1 else None     # None: equal slabs, plain all-gather
         self.local = [ctx.empty((nzl, nk)) for _ in range(2 * len(self.pairs))]
         if self._gather:
             self.full = [ctx.empty((nz_total, nk)) for _ in range(2 * len(self.pairs))]
@@ -203,14 +232,15 @@ class ShardedSpectra:
         xGMI the all-gather of a 0.1 ms slab step would otherwise be a visible fraction of it."""
         if not self._gather:
             return
+        kw = {} if self.counts is None else {"counts": self.counts}
         if hasattr(self.comm, "gather_rows_async"):
-            self.comm.gather_rows_async(self.local, self.full, self._EV_SPECTRA, self._EV_GATHERED, self._COMM_LANE)
+            self.comm.gather_rows_async(self.local, self.full, self._EV_SPECTRA, self._EV_GATHERED, self._COMM_LANE, **kw)
             return
         ctx = self.model._ctx()            # communicators without the fused entry point (tests/helpers)
         ctx.record(self._EV_SPECTRA)
         ctx.lane(self._COMM_LANE)
         ctx.wait(self._EV_SPECTRA)
-        self.comm.allgather_rows(self.local, self.full)
+        self.comm.allgather_rows(self.local, self.full, **kw)
         ctx.record(self._EV_GATHERED)
         ctx.lane(0)
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMG_ABI_VERSION 5
+#define HMG_ABI_VERSION 6
 
 typedef struct hmg_ctx hmg_ctx;
 
@@ -500,6 +500,15 @@ int hmg_comm_allgather_multi(hmg_ctx* ctx, int n, const double* const* h_d_send,
  * hmg_event_wait(done_slot) on the compute lane orders the next overwrite of the send buffers.   */
 int hmg_comm_gather_async(hmg_ctx* ctx, int n, const double* const* h_d_send, double* const* h_d_recv,
                           size_t count_per_rank, int ready_slot, int done_slot, int comm_lane);
+/* Slabs of unequal length (nz not a multiple of the number of ranks: SURVEY 8e partitions "contiguous z-slabs";
+ * the README grid has nz = 20, /root/reference/README.rst:55): rank r contributes h_counts[r] doubles per array,
+ * which land at the prefix-sum offset of every rank's receive buffer - one ncclBroadcast per (array, rank) in one
+ * group launch.  h_counts has one entry per rank and must be the same on every rank; equal counts take the
+ * all-gather of the entry points above. */
+int hmg_comm_allgatherv_multi(hmg_ctx* ctx, int n, const double* const* h_d_send, double* const* h_d_recv,
+                              const size_t* h_counts);
+int hmg_comm_gatherv_async(hmg_ctx* ctx, int n, const double* const* h_d_send, double* const* h_d_recv,
+                           const size_t* h_counts, int ready_slot, int done_slot, int comm_lane);
 /* rank and size as RCCL reports them (ncclCommUserRank / ncclCommCount); 0 and 1 without a communicator */
 int hmg_comm_info(hmg_ctx* ctx, int* h_rank, int* h_nranks);
 int hmg_comm_barrier(hmg_ctx* ctx);     /* blocks */

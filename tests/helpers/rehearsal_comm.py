@@ -47,13 +47,14 @@ class HostRehearsalComm:
             os.remove(old)
         return parts
 
-    def allgather_rows(self, sends, recvs):
+    def allgather_rows(self, sends, recvs, counts=None):
         self.ctx.sync()                               # (blocking by design: the lanes are drained first)
         flat = np.concatenate([s.numpy().reshape(-1) for s in sends])
         parts = self.exchange(flat)
-        n = sends[0].size
         for i, rcv in enumerate(recvs):
-            full = np.concatenate([p[i * n:(i + 1) * n] for p in parts])
+            # rank r's part holds len(sends) arrays of its own slab length (unequal slabs: counts[r])
+            full = np.concatenate([p[i * (p.size // len(sends)):(i + 1) * (p.size // len(sends))] for p in parts])
+            assert counts is None or [p.size // len(sends) for p in parts] == list(counts)
             nat.check(self.ctx.lib.hmg_memcpy_h2d(self.ctx.handle, rcv.ptr, full.ctypes.data, full.nbytes))
 
     def allgather_host(self, values):

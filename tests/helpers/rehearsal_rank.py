@@ -1,6 +1,6 @@
 """One rank of the two-process z-slab run (tests/test_gpu_comm.py): builds the model of its slab, runs the
 sharded spectra through the named transport and saves what the gather left in its full-grid buffers.
-argv: rank world tag directory out.npz [transport]
+argv: rank world tag directory out.npz [transport [nz]]
 transport "files" (default): every rank on device 0, exchange through tests/helpers/rehearsal_comm.py (a one-GPU
 box); "rccl": rank r on device r, the product's RcclComm (needs as many devices as ranks)."""
 import os
@@ -17,7 +17,7 @@ from rehearsal_comm import HostRehearsalComm             # noqa: E402
 
 rank, world, tag, directory, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
 transport = sys.argv[6] if len(sys.argv) > 6 else "files"
-zs = np.linspace(0.1, 2.6, 8)
+zs = np.linspace(0.1, 2.6, int(sys.argv[7]) if len(sys.argv) > 7 else 8)
 ms = np.geomspace(2e10, 1e16, 96)
 ks = np.geomspace(1e-3, 50, 384)
 PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("g", "electron"), ("nfw", "electron")]

@@ -64,11 +64,22 @@ class GlooComm:
     def __init__(self):
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def allgather_rows(self, sends, recvs):
+    def allgather_rows(self, sends, recvs, counts=None):
         for s, r in zip(sends, recvs):
-            out = torch.empty(r.shape, dtype=torch.float64)
-            dist.all_gather_into_tensor(out, torch.from_numpy(s.a))
-            r.a[...] = out.numpy()
+            if counts is None:
+                out = torch.empty(r.shape, dtype=torch.float64)
+                dist.all_gather_into_tensor(out, torch.from_numpy(s.a))
+                r.a[...] = out.numpy()
+                continue
+            # unequal slabs: one broadcast per rank into its prefix-sum offset - what hmg_comm_allgatherv_multi
+            # does with ncclBroadcast
+            flat, off = r.a.reshape(-1), 0
+            for root, cnt in enumerate(counts):
+                t = torch.from_numpy(s.a.reshape(-1).copy()) if root == self.rank else torch.empty(cnt, dtype=torch.float64)
+                assert t.numel() == cnt
+                dist.broadcast(t, src=root)
+                flat[off:off + cnt] = t.numpy()
+                off += cnt
 
     def barrier(self):
         dist.barrier()
@@ -94,7 +105,7 @@ def main():
     out_dir = sys.argv[1]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    zs = np.linspace(0.05, 2.5, 6)
+    zs = np.linspace(0.05, 2.5, int(sys.argv[2]) if len(sys.argv) > 2 else 6)
     ms = np.geomspace(1e11, 1e16, 20)
     ks = np.geomspace(1e-3, 10, 24)
     pairs = [("nfw", "nfw"), ("g", "electron"), ("g", "g")]

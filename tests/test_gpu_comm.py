@@ -26,6 +26,14 @@ def test_single_rank_communicator_roundtrip(tmp_path, monkeypatch):
         assert np.array_equal(r.numpy(), x)
     got = comm.allgather_host([1.5, -2.0])
     assert got.shape == (1, 2) and np.array_equal(got[0], [1.5, -2.0])
+    # the per-rank-count entry point with one rank (counts given explicitly through the C ABI)
+    import ctypes as C
+    r2 = [ctx.empty((3, 17)) for _ in a]
+    sp = (C.c_void_p * 4)(*[s.ptr for s in sends])
+    rp = (C.c_void_p * 4)(*[r.ptr for r in r2])
+    ctx.call("hmg_comm_allgatherv_multi", 4, sp, rp, (C.c_size_t * 1)(51))
+    for x, r in zip(a, r2):
+        assert np.array_equal(r.numpy(), x)
     comm.close()
     assert not any(f.startswith("hmg_rdzv_") for f in os.listdir(tmp_path))   # rendezvous file removed
     ctx.close()
@@ -81,9 +89,9 @@ def _device_count():
     return n.value if rc == 0 else 0
 
 
-def _full_grid_reference():
+def _full_grid_reference(nz=8):
     import hmvec_amd as hm
-    zs = np.linspace(0.1, 2.6, 8)
+    zs = np.linspace(0.1, 2.6, nz)
     ms = np.geomspace(2e10, 1e16, 96)
     ks = np.geomspace(1e-3, 50, 384)
     h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
@@ -95,8 +103,10 @@ def _full_grid_reference():
     return pairs, {p: (a.copy(), b.copy()) for p, (a, b) in blk.fetch().items()}
 
 
-def test_two_rank_rccl_gather_reproduces_the_full_grid(tmp_path):
-    """Config 4 in small: two ranks on two devices, z-slabs joined by the product's grouped RCCL all-gather
+@pytest.mark.parametrize("nz", [8, 7])
+def test_two_rank_rccl_gather_reproduces_the_full_grid(tmp_path, nz):
+    """(nz = 7: unequal slabs of 4 and 3 redshifts, gathered with per-rank counts - grouped ncclBroadcast.)
+    Config 4 in small: two ranks on two devices, z-slabs joined by the product's grouped RCCL all-gather
     over xGMI; every rank's gathered buffers equal the one-process full grid bit for bit.  Needs two visible
     devices (the development boxes have one: skipped there, runs wherever the hardware is)."""
     import subprocess
@@ -107,8 +117,8 @@ def test_two_rank_rccl_gather_reproduces_the_full_grid(tmp_path):
     worker = os.path.join(here, "helpers", "rehearsal_rank.py")
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HMG_RDZV_TIMEOUT="120")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"rccl{os.getpid()}", str(tmp_path), outs[r], "rccl"],
-                              env=env) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"rccl{os.getpid()}_{nz}", str(tmp_path), outs[r], "rccl",
+                               str(nz)], env=env) for r in range(2)]
     try:
         for p in procs:
             assert p.wait(timeout=300) == 0
@@ -116,7 +126,7 @@ def test_two_rank_rccl_gather_reproduces_the_full_grid(tmp_path):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    pairs, ref = _full_grid_reference()
+    pairs, ref = _full_grid_reference(nz)
     for r in range(2):
         got = np.load(outs[r])
         assert len(got.files) == 2 * len(pairs)
@@ -125,8 +135,9 @@ def test_two_rank_rccl_gather_reproduces_the_full_grid(tmp_path):
             assert np.array_equal(got[key], ref[(a, b)][int(i)]), (r, key)
 
 
-def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path):
-    """The N > 1 data path minus RCCL itself (which refuses two ranks on one device): two processes, each
+@pytest.mark.parametrize("nz", [8, 7])
+def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path, nz):
+    """(nz = 7: unequal slabs.)  The N > 1 data path minus RCCL itself (which refuses two ranks on one device): two processes, each
     with the model of its z-slab, exchange through the file transport of tests/helpers/rehearsal_comm.py; what the
     gather leaves in EVERY rank's full-grid buffers is, bit for bit, what one process computes on the
     full redshift grid - slabs land in place and a slab reproduces its rows of the full grid exactly."""
@@ -135,11 +146,11 @@ def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path):
     here = os.path.dirname(os.path.abspath(__file__))
     worker = os.path.join(here, "helpers", "rehearsal_rank.py")
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"t{os.getpid()}", str(tmp_path), outs[r]])
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", f"t{os.getpid()}_{nz}", str(tmp_path), outs[r], "files", str(nz)])
              for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    pairs, ref = _full_grid_reference()
+    pairs, ref = _full_grid_reference(nz)
     for r in range(2):
         got = np.load(outs[r])
         assert len(got.files) == 2 * len(pairs)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import REPO
-from hmvec_amd.dist import slab_bounds
+from hmvec_amd.dist import slab_bounds, slab_counts
 
 
 def free_port():
@@ -22,18 +22,28 @@ def free_port():
 def test_slab_bounds():
     assert [slab_bounds(32, 8, r) for r in (0, 3, 7)] == [(0, 4), (12, 16), (28, 32)]
     assert slab_bounds(20, 1, 0) == (0, 20)
+    # nz need not divide: the README grid (nz = 20) on 8 ranks - four slabs of 3, four of 2, contiguous, in order
+    b = [slab_bounds(20, 8, r) for r in range(8)]
+    assert b == [(0, 3), (3, 6), (6, 9), (9, 12), (12, 14), (14, 16), (16, 18), (18, 20)]
+    assert slab_counts(20, 8) == [3, 3, 3, 3, 2, 2, 2, 2] and slab_counts(5, 2) == [3, 2]
+    for nz, world in ((7, 3), (33, 8), (8, 8), (9, 8)):
+        bb = [slab_bounds(nz, world, r) for r in range(world)]
+        assert bb[0][0] == 0 and bb[-1][1] == nz and all(x[1] == y[0] for x, y in zip(bb, bb[1:]))
+        assert max(h - l for l, h in bb) - min(h - l for l, h in bb) <= 1
     with pytest.raises(ValueError):
-        slab_bounds(20, 8, 0)          # equal-count all-gather needs nz % world == 0
+        slab_bounds(3, 8, 0)           # a rank would own no redshift
 
 
-def test_two_rank_zslab_gather_matches_full_grid(tmp_path):
+@pytest.mark.parametrize("nz", [6, 5])
+def test_two_rank_zslab_gather_matches_full_grid(tmp_path, nz):
+    """nz = 6: equal slabs (one all-gather); nz = 5: slabs of 3 and 2 redshifts (per-rank counts)."""
     port = free_port()
     worker = os.path.join(REPO, "tests", "helpers", "shard_worker.py")
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path)], env=env,
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), str(nz)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=240)
