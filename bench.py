@@ -39,7 +39,7 @@ PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"),
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_CYCLES = 4      # a wave64 fp64 VALU instruction occupies its SIMD-32 for 4 cycles
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-PROFILE_DIR = os.path.join(REPO, "profiles", "r03")
+PROFILE_DIR = os.path.join(REPO, "profiles", "r04")
 BRACKET_EVERY = int(os.environ.get("HMG_BENCH_BRACKET_EVERY", "8"))   # kernel-level HIP events ride on every 8th timed step
 
 
@@ -242,6 +242,74 @@ def cpu_baseline(zs, ms, ks, nz_sample, nxs, allcore=True, xmax=20.0):
 
 
 # ------------------------------------------------------------------------------------------------
+# BASELINE configs[0]/[1]: the README usage sequence on 20 x 200 x 1001 (README.rst:52-90)
+# ------------------------------------------------------------------------------------------------
+def readme_config2(ctx, with_cpu=True):
+    """Facade wall time (host work included) of the README sequence - constructor, add_battaglia_profile(nxs=5000),
+    add_hod, twelve get_power_1halo/_2halo calls returning host arrays - on the reference's own grid, its parity
+    against the strided sample of the UNMODIFIED reference's run (tests/golden/readme_c1.npz) and the oracle's time
+    for the same sequence on this box's host."""
+    import hmvec_amd as hm
+    from hmvec_amd.params import battaglia_defaults, default_params
+    zs = np.linspace(0., 3., 20); ms = np.geomspace(2e10, 1e17, 200); ks = np.geomspace(1e-4, 100, 1001)
+    names = ["nfw", "electron", "g"]
+    pairs = [(a, b) for i, a in enumerate(names) for b in names[i:]]
+
+    def seq():
+        t0 = time.perf_counter()
+        h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic", ctx=ctx)
+        t1 = time.perf_counter()
+        h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=5000)
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.)
+        out = {}
+        for a, b in pairs:
+            out[(a, b)] = (h.get_power_1halo(a, b), h.get_power_2halo(a, b))
+        t2 = time.perf_counter()
+        return h, out, (t1 - t0, t2 - t1)
+
+    seq(); seq()                                  # first launches, pinned staging, FFT tables
+    runs = [seq() for _ in range(7)]
+    h, out, _ = runs[-1]
+    tc = sorted(r[2][0] for r in runs)[len(runs) // 2]
+    tr = sorted(r[2][1] for r in runs)[len(runs) // 2]
+    rec = {"grid": "zs=20 (0..3) ms=200 ks=1001, analytic NFW + Battaglia AGN nxs=5000 xmax=20 + HOD(mthresh=10^10.5)",
+           "ctor_ms": tc * 1e3, "profiles_hod_12_get_power_ms": tr * 1e3, "sequence_ms": (tc + tr) * 1e3,
+           "timing": "median of 7 sequences after 2 warm-up sequences; host wall incl. the provider's numpy, uploads "
+                     "and the twelve (nz,nk) results copied to the host",
+           "grid_points_per_s": len(pairs) * zs.size * ms.size * ks.size / (tc + tr)}
+    gpath = os.path.join(REPO, "tests", "golden", "readme_c1.npz")
+    if os.path.exists(gpath):
+        with np.load(gpath, allow_pickle=False) as g:
+            ki = slice(None, None, int(g["kstride"]))
+            worst = 0.0
+            for (a, b), (p1, p2) in out.items():
+                for got, key in ((p1, f"P1h_{a}_{b}"), (p2, f"P2h_{a}_{b}")):
+                    R = g[key]
+                    tol = 1e-8 * np.abs(R) + 1e-12 * np.max(np.abs(R), axis=-1, keepdims=True)
+                    worst = max(worst, float(np.max(np.abs(got[:, ki] - R) / tol)))
+        rec["parity_worst_dP_over_tol"] = worst
+        rec["parity_against"] = "tests/golden/readme_c1.npz: the unmodified reference's run of this sequence, every 20th k"
+    if with_cpu:
+        from oracle import hmref
+        p = dict(default_params)
+        ksig = np.geomspace(p["sigma2_kmin"], p["sigma2_kmax"], p["sigma2_numks"])
+        t0 = time.perf_counter()
+        ci = hmref.CosmoInputs(h=h.h, omm0=h.omm0, ombh2=p["ombh2"], rho_crit_0=float(h.rho_critical_z(0.0)),
+                               rho_crit_zs=h.rho_critical_z(zs), Pzk=h.Pzk, sPzk=h.sPzk, ks_sigma2=ksig,
+                               h_of_z_zs=h.h_of_z(zs))
+        o = hmref.RefHaloModel(ci, zs, ks, ms, p)
+        t1 = time.perf_counter()
+        o.add_battaglia_profile("electron", "AGN", p["battaglia_gas_gamma"], battaglia_defaults["AGN"], 5000, 20)
+        o.add_hod("g", mthresh=10 ** 10.5 + zs * 0.)
+        for a, b in pairs:
+            o.get_power_1halo(a, b); o.get_power_2halo(a, b)
+        t2 = time.perf_counter()
+        rec["cpu_oracle"] = {"ctor_ms": (t1 - t0) * 1e3, "rest_ms": (t2 - t1) * 1e3, "sequence_ms": (t2 - t0) * 1e3,
+                             "cores": 1, "kind": "port", "sample": "the whole sequence, one run"}
+    return rec
+
+
+# ------------------------------------------------------------------------------------------------
 # byte and instruction models of the three large kernels
 # ------------------------------------------------------------------------------------------------
 def load_profile(name):
@@ -286,6 +354,8 @@ def main():
     ap.add_argument("--lanes", action="store_true",
                     help="independent stages on separate HIP streams (concurrent graph branches)")
     ap.add_argument("--per-pair", action="store_true", help="six hmg_power launches instead of one hmg_power_batch")
+    ap.add_argument("--no-readme", action="store_true",
+                    help="skip the BASELINE configs[0]/[1] block (README sequence on 20 x 200 x 1001)")
     ap.add_argument("--no-limber", action="store_true",
                     help="skip the Config-5 leg (C_kk and C_kg at 2000 multipoles on the gathered spectra)")
     ap.add_argument("--stages", action="store_true",
@@ -451,7 +521,7 @@ def main():
         return
 
     # ---- bytes: the implementation's own model and, for the default configuration,
-    # the PMC counters of profiles/r03 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+    # the PMC counters of profiles/r04 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
     default_cfg = ((args.nz, args.nm, args.nk, args.nxs, args.xmax) == (32, 512, 4096, 5000, 20.0) and world == 1
                    and not args.per_pair)
     sha = nat.kernel_source_sha16()
@@ -505,7 +575,7 @@ def main():
         ms_ = kms[key]
         moved = pmc_bytes(sub) or model[key]
         e = {"bound": bound, "ms": ms_, "bytes_moved": moved,
-             "bytes_source": "pmc (profiles/r03/pmc_traffic.json)" if pmc_bytes(sub) else "model (DESIGN.md section 4)",
+             "bytes_source": "pmc (profiles/r04/pmc_traffic.json)" if pmc_bytes(sub) else "model (DESIGN.md section 4)",
              "bytes_model": model[key], "hbm_GBps": moved / (ms_ * 1e-3) / 1e9 if ms_ else None,
              "hbm_frac": moved / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ else None,
              "survey_alg_bytes": alg[key], "note": note}
@@ -565,12 +635,75 @@ def main():
             keep = [ctx.upload(a) for a in ins]
         ctx.sync()
         h2d_ms = (time.perf_counter() - t1) / 5 * 1e3
-        pcie = {"d2h_results_ms": d2h_ms, "h2d_inputs_ms": h2d_ms, "results_MB": blk.nbytes / 1e6,
+        # the same inputs staged in page-locked memory: asynchronous DMAs at link speed, no bounce copies
+        pins = [nat.PinnedArray(ctx, a.shape) for a in ins]
+        for pa, a in zip(pins, ins):
+            pa.array[...] = a
+        dsts = [ctx.empty(a.shape) for a in ins]
+        for d_, pa in zip(dsts, pins):
+            ctx.copy_from_pinned(d_, pa)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            for d_, pa in zip(dsts, pins):
+                ctx.copy_from_pinned(d_, pa)
+        ctx.sync()
+        h2d_pinned_ms = (time.perf_counter() - t1) / 5 * 1e3
+        assert all(np.array_equal(d_.numpy(), a) for d_, a in zip(dsts, ins))
+
+        # ---- streamed hand-over: a double-buffered result block; pass i's copy to the host runs on the copy lane
+        # under pass i+1's kernels, the host consumes pass i-1 meanwhile.  Same kernels, same numbers.
+        streamed = None
+        if use_graph:
+            blk2 = h.spectra_block(PAIRS, nbuf=2)
+
+            def pass_into(slot):
+                h.init_mass_function(ms)
+                h.add_nfw_profile("nfw", ignore_existing=True)
+                h.add_battaglia_profile("electron", family="AGN", xmax=args.xmax, nxs=args.nxs, ignore_existing=True)
+                h.add_hod("g", mthresh=mthr, ignore_existing=True)
+                blk2.compute(slot)
+            for slot in (0, 1):
+                pass_into(slot)
+            ctx.sync()
+            g2 = [ctx.capture(lambda slot=slot: pass_into(slot)) for slot in (0, 1)]
+            consumed = [0.0]
+
+            def stream(nsteps):
+                for s_ in range(nsteps):
+                    slot = s_ % 2
+                    if s_ >= 2:
+                        ctx.wait(blk2._EV_DONE + slot)          # device-side: the block's last copy has left
+                    ctx.replay(g2[slot])
+                    blk2.fetch_async(slot)
+                    if s_ >= 1:                                  # the host reads pass s-1 while pass s runs
+                        got = blk2.wait((s_ - 1) % 2)
+                        consumed[0] += float(got[PAIRS[0]][0][0, 0])
+                got = blk2.wait((nsteps - 1) % 2)
+                return got
+            stream(8)
+            ctx.sync()
+            t1 = time.perf_counter()
+            last = stream(K)
+            ctx.sync()
+            st_ms = (time.perf_counter() - t1) / K * 1e3
+            res_now = spec.results()
+            same = all(np.array_equal(last[p_][i], res_now[p_][i]) for p_ in PAIRS for i in (0, 1))
+            streamed = {"ms_per_step_incl_results": st_ms, "bit_equal_to_timed_outputs": bool(same),
+                        "note": "K passes, each computing into one of two device result blocks and copied to its pinned "
+                                "twin on the copy lane behind an event; the host waits for and reads pass i-1 while pass "
+                                "i runs (hmg_event_synchronize on that copy only)"}
+        pcie = {"d2h_results_ms": d2h_ms, "h2d_inputs_ms": h2d_ms, "h2d_inputs_pinned_ms": h2d_pinned_ms,
+                "results_MB": blk.nbytes / 1e6,
                 "inputs_MB": sum(a.nbytes for a in ins) / 1e6,
                 "d2h_GBps": blk.nbytes / d2h_ms / 1e6,
                 "ms_per_step_incl_transfers": dt_max / K * 1e3 + d2h_ms + h2d_ms,
+                "streamed": streamed,
                 "note": "results: 12 (nz,nk) spectra in one device block, one asynchronous copy into one pinned host "
-                        "block, numpy views handed out (HaloModel.spectra_block); inputs: pageable numpy uploads"}
+                        "block, numpy views handed out (HaloModel.spectra_block); inputs: pageable numpy uploads "
+                        "(h2d_inputs_ms) and the same arrays staged in pinned memory (h2d_inputs_pinned_ms). "
+                        "ms_per_step_incl_transfers serialises step + copies; `streamed` overlaps the result copy with "
+                        "the next pass"}
         del keep
 
     # ---- Config 5: Limber C_kk + C_kg at 2000 multipoles on the gathered, device-resident spectra
@@ -618,20 +751,23 @@ def main():
         "roofline": {"kernel": "hmg::power_batch_kernel" if not args.per_pair else "hmg::power_kernel x6 (per-pair path)",
                      "bound": "hbm", "achieved": pw["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": pw["hbm_frac"], "traffic": pmc_bytes("power_batch_kernel"),
-                     "traffic_source": ("stored profile profiles/r03/pmc_traffic.json of this build: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                     "traffic_source": ("stored profile profiles/r04/pmc_traffic.json of this build: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                         "separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch "
                                         "(gfx950 FETCH_SIZE correction)") if pmc else None,
                      "bytes_moved": pw["bytes_moved"], "bytes_source": pw["bytes_source"], "bytes_model": pw["bytes_model"],
                      "ms_per_launch": kms["power"],
                      "alg_bytes_per_launch": alg["power"],
                      "alg_equiv_GBps": alg["power"] / (kms["power"] * 1e-3) / 1e9 if kms["power"] else None,
-                     "note": "achieved/frac use the bytes the launch actually moves (counter bytes when a profile of this "
+                     "note": "this block is the dominant HBM-BOUND kernel; the kernel the step spends most TIME in is fp64-VALU/LDS "
+                             "bound and has its own block, roofline_time_dominant.  achieved/frac use the bytes the launch actually moves (counter bytes when a profile of this "
                              "configuration is stored, else the launch's own skip rule evaluated on the hint array); "
                              "alg_equiv_GBps prices the SURVEY 8d algorithmic bytes, of which the hinted constant prefix "
                              "is never read"},
         "roofline_time_dominant": roofline_time_dominant,
         "kernels": kernels,
-        "launches_per_step": 4 if grouped else 8,
+        "launches_per_step": (ctx.graph_kernel_nodes(g_plain) if g_plain is not None else None),
+        "launches_per_step_source": ("kernel nodes of the captured step (hipGraphGetNodes), counted by the library at capture end"
+                                     if g_plain is not None else "not counted: eager launches (--no-graph / --stages)"),
         "launch_grouping": ("front (sigma^2 contraction | halo stage | HOD occupations), rows group, profile group, "
                             "mass integrals" if grouped else "one launch per stage (HMG_NO_GROUPS=1)"),
         "kernel_source_sha16": sha, "stale_profiles_ignored": stale or None,
@@ -642,6 +778,8 @@ def main():
     if args.stages and stage_ms:
         out["stages_ms"] = dict(zip(["mass_function", "nfw", "battaglia_fft", "hod", "spectra"],
                                     np.mean(np.array(stage_ms), axis=0).tolist()))
+    if world == 1 and not args.no_readme:
+        out["readme_config2"] = readme_config2(ctx, with_cpu=not args.no_cpu_baseline)
     if pcie is not None:
         out["pcie"] = pcie
     if limber is not None:

@@ -125,9 +125,12 @@ SIGNATURES = {
     "hmg_host_alloc": [_P, _Z, C.POINTER(_P)],
     "hmg_host_free": [_P, _P],
     "hmg_memcpy_d2h_async": [_P, _P, _P, _Z],
+    "hmg_memcpy_h2d_async": [_P, _P, _P, _Z],
+    "hmg_event_synchronize": [_P, _I],
     "hmg_graph_begin": [_P],
     "hmg_graph_end": [_P, C.POINTER(_I)],
     "hmg_graph_abort": [_P],
+    "hmg_graph_kernel_nodes": [_P, _I, C.POINTER(_I)],
     "hmg_graph_launch": [_P, _I],
     "hmg_graph_destroy": [_P, _I],
     "hmg_lane_set": [_P, _I],
@@ -451,6 +454,12 @@ class Context:
             self.capture_serial += 1
         return gid.value
 
+    def graph_kernel_nodes(self, gid):
+        """Kernel launches the captured step `gid` holds."""
+        n = C.c_int()
+        check(self.lib.hmg_graph_kernel_nodes(self.handle, gid, C.byref(n)))
+        return n.value
+
     def replay(self, gid):
         self.flush()
         self.call_now("hmg_graph_launch", gid)
@@ -459,6 +468,16 @@ class Context:
         """Asynchronous D2H of DeviceArray ``src`` into PinnedArray ``pinned`` on the current lane."""
         self.flush()
         self.call_now("hmg_memcpy_d2h_async", pinned.ptr, src.ptr, src.nbytes)
+
+
+    def copy_from_pinned(self, dst, pinned):
+        """Asynchronous H2D of PinnedArray ``pinned`` into DeviceArray ``dst`` on the current lane."""
+        self.flush()
+        self.call_now("hmg_memcpy_h2d_async", dst.ptr, pinned.ptr, dst.nbytes)
+
+    def event_synchronize(self, slot):
+        """Block the host until the event last recorded in ``slot`` has happened (other work keeps running)."""
+        check(self.lib.hmg_event_synchronize(self.handle, slot))
 
 
 _default_ctx = {}

@@ -142,6 +142,7 @@ struct hmg_ctx {
     std::vector<void*> freed_in_capture;           // hmg_free calls that arrived during a capture ...
     std::map<int, std::vector<void*>> graph_blocks; // ... stay with the graph that may use them until it is destroyed
     std::map<int, hipGraphExec_t> graphs;
+    std::map<int, int> graph_kernels;              // kernel nodes per captured graph
     int next_graph_id = 1;
     hmg_ctx() { for (auto& b : bracket) b[0] = b[1] = -1; }
 };
@@ -3144,6 +3145,18 @@ int hmg_memcpy_d2h_async(hmg_ctx* c, void* h_pinned, const void* d, size_t bytes
     HIP_TRY(hipMemcpyAsync(h_pinned, d, bytes, hipMemcpyDeviceToHost, c->stream));
     return 0;
 }
+int hmg_memcpy_h2d_async(hmg_ctx* c, void* d, const void* h_pinned, size_t bytes) {
+    REQUIRE(c && h_pinned && d, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(d, h_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int hmg_event_synchronize(hmg_ctx* c, int slot) {
+    REQUIRE(c && slot >= 0 && slot < HMG_EVENT_SLOTS, "bad event slot");
+    REQUIRE(!c->capturing, "hmg_event_synchronize inside a captured step");
+    REQUIRE(c->ev[slot] != nullptr, "event slot was never recorded");
+    HIP_TRY(hipEventSynchronize(c->ev[slot]));
+    return 0;
+}
 constexpr size_t PIN_CHUNK = (size_t)8 << 20;   // 8 MiB per bounce buffer
 
 static int ensure_pinned(hmg_ctx* c) {
@@ -3297,6 +3310,19 @@ int hmg_graph_end(hmg_ctx* c, int* id) {
     c->stream = c->lanes[0];
     hipGraph_t g = nullptr;
     HIP_TRY(hipStreamEndCapture(c->lanes[0], &g));
+    // how many kernel launches the captured step holds (bench.py reports it as launches_per_step)
+    int nkern = 0;
+    {
+        size_t nn = 0;
+        if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess && nn) {
+            std::vector<hipGraphNode_t> nodes(nn);
+            if (hipGraphGetNodes(g, nodes.data(), &nn) == hipSuccess)
+                for (size_t i = 0; i < nn; ++i) {
+                    hipGraphNodeType t;
+                    if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++nkern;
+                }
+        }
+    }
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
@@ -3304,10 +3330,18 @@ int hmg_graph_end(hmg_ctx* c, int* id) {
     HIP_TRY(e);
     *id = c->next_graph_id++;
     c->graphs[*id] = ge;
+    c->graph_kernels[*id] = nkern;
     // A block handed back while the capture ran was allocated before it (allocation inside a capture is
     // refused) and may be an operand of a captured launch: it stays out of the free list as long as the
     // graph can be replayed.
     c->graph_blocks[*id].swap(c->freed_in_capture);
+    return 0;
+}
+int hmg_graph_kernel_nodes(hmg_ctx* c, int id, int* n) {
+    REQUIRE(c && n, "NULL argument");
+    auto it = c->graph_kernels.find(id);
+    REQUIRE(it != c->graph_kernels.end(), "unknown graph id");
+    *n = it->second;
     return 0;
 }
 int hmg_graph_abort(hmg_ctx* c) {      // leave capture mode after a failed call inside a capture

@@ -931,13 +931,13 @@ class HaloModel(Cosmology):
                 ctx.call("hmg_memcpy_d2d", o2[i].ptr, o2[first[u]].ptr, o2[i].nbytes)
         return o1, o2
 
-    def spectra_block(self, pairs):
+    def spectra_block(self, pairs, nbuf=1):
         """A reusable result block for several (name, name2) spectra: one contiguous device buffer
         for the 2*len(pairs) (nz,nk) outputs and one page-locked host buffer of the same shape.
         ``compute()`` enqueues the batched mass integrals into it, ``fetch()`` brings all of them to
         the host with ONE asynchronous copy at link speed and returns numpy views (valid until the
         next ``fetch`` of the same block).  For parameter sweeps that read every spectrum back."""
-        return SpectraBlock(self, pairs)
+        return SpectraBlock(self, pairs, nbuf)
 
     def get_power_all(self, pairs):
         """Extension of the reference API: {(name, name2): P_1h + P_2h} for several pairs in one
@@ -1078,30 +1078,63 @@ class HaloModel(Cosmology):
 
 
 class SpectraBlock:
-    """See HaloModel.spectra_block."""
+    """See HaloModel.spectra_block.  With ``nbuf=2`` the block is double-buffered for streams of passes (parameter
+    sweeps): ``compute(slot)`` enqueues pass i into device block i % 2, ``fetch_async(slot)`` sends it to its pinned
+    twin on the context's copy lane behind an event, and pass i+1's kernels run while that copy is in flight;
+    ``wait(slot)`` blocks the host on that one copy only and returns the views.  The next ``compute(slot)`` of the
+    same slot is ordered behind the copy on the device, so no result is overwritten before it has left."""
 
-    def __init__(self, model, pairs):
+    _COPY_LANE = 2
+    _EV_READY, _EV_DONE = 10, 12       # event slots 10-11, 12-13 (HaloModel: 0-3, ShardedSpectra: 8-9, bench.py: 40+)
+
+    def __init__(self, model, pairs, nbuf=1):
         self.model = model
         self.pairs = [(a, a if b is None else b) for a, b in pairs]
         ctx = model._ctx()
         nz, nk = model.zs.size, model.ks.size
         n = 2 * len(self.pairs)
-        self.dev = ctx.empty((n, nz, nk))
-        self.views = [self.dev.view(i * nz * nk, (nz, nk)) for i in range(n)]
-        self.host = nat.PinnedArray(ctx, (n, nz, nk))
+        self.nbuf = int(nbuf)
+        self._devs = [ctx.empty((n, nz, nk)) for _ in range(self.nbuf)]
+        self._views = [[d.view(i * nz * nk, (nz, nk)) for i in range(n)] for d in self._devs]
+        self._hosts = [nat.PinnedArray(ctx, (n, nz, nk)) for _ in range(self.nbuf)]
+        self._inflight = [False] * self.nbuf
+        self.dev, self.views, self.host = self._devs[0], self._views[0], self._hosts[0]
         self.nbytes = self.dev.nbytes
 
-    def compute(self):
-        """Launch-only: the spectra of all pairs into the device block."""
-        self.model.power_device_batch(self.pairs, self.views[0::2], self.views[1::2])
+    def compute(self, slot=0):
+        """Launch-only: the spectra of all pairs into device block `slot` (behind the copy that last read it)."""
+        if self._inflight[slot]:
+            self.model._ctx().wait(self._EV_DONE + slot)
+        self.model.power_device_batch(self.pairs, self._views[slot][0::2], self._views[slot][1::2])
 
-    def fetch(self):
+    def _as_dict(self, slot):
+        a = self._hosts[slot].array
+        return {p: (a[2 * i], a[2 * i + 1]) for i, p in enumerate(self.pairs)}
+
+    def fetch(self, slot=0):
         """{(name, name2): (P_1h, P_2h)} as views of the pinned host block; blocks until the copy lands."""
         ctx = self.model._ctx()
-        ctx.copy_to_pinned(self.host, self.dev)
+        ctx.copy_to_pinned(self._hosts[slot], self._devs[slot])
         ctx.sync()
-        a = self.host.array
-        return {p: (a[2 * i], a[2 * i + 1]) for i, p in enumerate(self.pairs)}
+        self._inflight[slot] = False
+        return self._as_dict(slot)
+
+    def fetch_async(self, slot=0):
+        """Start the copy of block `slot` on the copy lane, behind the launches enqueued so far; returns at once."""
+        ctx = self.model._ctx()
+        ctx.record(self._EV_READY + slot)
+        ctx.lane(self._COPY_LANE)
+        ctx.wait(self._EV_READY + slot)
+        ctx.copy_to_pinned(self._hosts[slot], self._devs[slot])
+        ctx.record(self._EV_DONE + slot)
+        ctx.lane(0)
+        self._inflight[slot] = True
+
+    def wait(self, slot=0):
+        """Views of block `slot` once its copy has landed (the device may already be busy with later passes)."""
+        if self._inflight[slot]:
+            self.model._ctx().event_synchronize(self._EV_DONE + slot)
+        return self._as_dict(slot)
 
 
 class _LazyArray:

@@ -52,6 +52,11 @@ int hmg_sync(hmg_ctx* ctx);                      /* waits for every lane */
 int hmg_host_alloc(hmg_ctx* ctx, size_t bytes, void** h_out);
 int hmg_host_free(hmg_ctx* ctx, void* h_ptr);
 int hmg_memcpy_d2h_async(hmg_ctx* ctx, void* h_pinned_dst, const void* d_src, size_t bytes);
+/* The same towards the device (inputs of a sweep staged in a page-locked block), and the host-side wait for ONE
+ * event - what a consumer of a streamed result block waits on while later passes keep running on the device
+ * (hmg_sync would wait for those too).  The reference hands host arrays in and out (hmvec/hmvec.py:76-94,500-572). */
+int hmg_memcpy_h2d_async(hmg_ctx* ctx, void* d_dst, const void* h_pinned_src, size_t bytes);
+int hmg_event_synchronize(hmg_ctx* ctx, int slot);     /* blocks until the event last recorded in `slot` has happened */
 /* Lanes: HMG_LANES HIP streams per context.  Every entry point enqueues on the CURRENT lane
  * (default 0).  Independent stages of the path (e.g. the NFW kernel and the profile-FFT kernel,
  * or the small per-(z,m) kernels) may be put on different lanes and ordered with events:
@@ -82,6 +87,7 @@ int hmg_bracket_next(hmg_ctx* ctx, int kernel_id, int slot_start, int slot_stop)
 int hmg_graph_begin(hmg_ctx* ctx);
 int hmg_graph_end(hmg_ctx* ctx, int* h_graph_id);
 int hmg_graph_abort(hmg_ctx* ctx);                 /* leave capture mode after a failed call */
+int hmg_graph_kernel_nodes(hmg_ctx* ctx, int graph_id, int* h_n);  /* kernel launches the captured step holds */
 int hmg_graph_launch(hmg_ctx* ctx, int graph_id);  /* on the current lane */
 int hmg_graph_destroy(hmg_ctx* ctx, int graph_id);
 
