@@ -110,6 +110,7 @@ struct hmg_ctx {
     size_t fft_chunk_bytes = 0;                    // 0 = default
     int use_fused_fft = 1;                         // HMG_FUSED_FFT=0 forces the rocFFT path
     int use_pruned_fft = 1;                        // HMG_PRUNED_FFT=0: long grids go to rocFFT as before round 4
+    int fused_max_m = 6144;                        // HMG_FUSED_MAX_M: longest packed row the one-row-in-LDS kernel takes
     int pruned_lp_min = 0;                         // HMG_PRUNED_LP_MIN: smallest sub-transform length to consider
     std::map<int, PrunedPlan> pruned;              // nxs -> tables of the pruned long-grid route
     std::map<SupportKey, int> support;             // last measured support bound (packed samples) of a launch's rows
@@ -1153,9 +1154,38 @@ __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ t
     __syncthreads();
 }
 
+// The passes of a length-M transform whose plan the compiler knows (ldsfft.hpp: SubPass<M, PS>): strides, twiddle
+// steps and index multipliers are immediates, every pass gets the butterflies-per-thread count it needs, and the
+// pass loop with its radix dispatch is gone - what the run-time plan pays in registers (116 B/lane of scratch in
+// round 3's profile_group_kernel<*,*,0>) and scalar instructions.
+template <int NT, int M, int PS>
+__device__ __forceinline__ void fused_passes_ct(cplx* buf, const cplx* __restrict__ twM, bool pruned, int jn) {
+    if constexpr (PS < SubPass<M, 0>::P.npass) {
+        using S = SubPass<M, PS>;
+        constexpr int MAXB = (S::nb + NT - 1) / NT;
+        // the last pass only has to produce Z[0..jn] and Z[M-jn..M-1]
+        const int keep = (S::last && 2 * jn + 2 < S::nb) ? jn : -1;
+        if (!(PS == 0 && pruned)) fused_pass<NT, S::R, MAXB, S::SMALL>(buf, twM, M, S::Ns, S::tws, S::mg, keep);
+        fused_passes_ct<NT, M, PS + 1>(buf, twM, pruned, jn);
+    }
+}
+template <int SPECM> constexpr int fused_first_radix() {
+    if constexpr (SPECM == 0) return 0; else return SubPass<SPECM, 0>::R;
+}
+
 #ifndef HMG_FUSED_OCC
 #define HMG_FUSED_OCC 8
 #endif
+// waves per SIMD a fused-row launch is compiled for: 8 with a compile-time plan (<= 64 VGPRs, no spill).  The
+// run-time plan needs ~91 registers for its pass loop and dispatch chain; measured on the Config-3 grid at
+// nxs = 3000 / 2000 (tools/shape_sweep.py): 8 waves/SIMD (64 VGPRs, 28-34 spilled, 116 B/lane) 0.294 / 0.277 ms,
+// 6 (80 VGPRs, 12 spilled, 52 B/lane) 0.263 / 0.243 ms, 5 (91 VGPRs, nothing spilled) 0.320 / 0.285 ms: 6 it is.
+// The lengths people use have compile-time plans (nxs = 1000, 2000, 4000, 5000, 10000: 0.131, 0.154, 0.193 ms
+// against 0.245, 0.285, 0.342 with the run-time plan), so this path serves the odd ones.
+#ifndef HMG_RT_OCC
+#define HMG_RT_OCC 6
+#endif
+template <int MAXB, int SPECM> constexpr int fused_occ() { return MAXB > 2 ? 4 : (SPECM ? HMG_FUSED_OCC : HMG_RT_OCC); }
 // SPECM != 0: the plan is known at compile time (SPECM = 2500, passes 4,5,5,5,5: nxs = 5000, the default
 // length of the Battaglia profiles) - strides, twiddle steps and the j/Ns multipliers become immediates and
 // the pass loop with its dispatch chain unrolls.
@@ -1239,7 +1269,7 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // sees (v0, 0, ..., 0) in every butterfly, whose DFT is v0 in all R0 outputs - exactly, in
     // floating point - so phase A writes each sample straight into its R0 output slots and the
     // pass (an LDS round trip, two barriers, the zero fill of the rest of the row) is skipped.
-    const int R0 = SPECM ? 4 : A.plan.radix[0];
+    const int R0 = SPECM ? fused_first_radix<SPECM>() : A.plan.radix[0];
     const int stride0 = M / R0;
     const bool pruned = (SPECM || A.plan.npass > 1) && A.xs[2 * stride0] > cm;   // xs is increasing
     // compile-time plan: when the row is zero from sample 375 on, the pass behind the pruned one reads samples
@@ -1259,13 +1289,13 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
 #endif
         const cplx y = cplx{xv.x * r0, xv.y * r1};
-        if (pruned && !SPECM) {
+        if (pruned && SPECM != 2500) {
             // the R0 copies go out in an order rotated by lane/4: with t the same in every lane, lanes l and l+4
             // (64 B apart) hit the same LDS banks and every one of these 16-B stores takes two passes
             const int rot = (threadIdx.x >> 2);
             for (int t = 0; t < R0; ++t) buf[R0 * p + (t + rot) % R0] = y;
         } else {
-            // (the compile-time plan replicates nothing: its second pass reads slot i as sample i >> 2)
+            // (the hand-sequenced 2500 plan replicates nothing: its second pass reads slot i as sample i >> 2)
             buf[p] = y;
         }
         if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
@@ -1313,6 +1343,8 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 20, 25, mg20, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 100, 5, mg100, -1);
         fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
+    } else if constexpr (SPECM != 0) {
+        fused_passes_ct<NT, SPECM, 0>(buf, A.twM, pruned, jn);
     } else
     for (int ps = pruned ? 1 : 0; ps < A.plan.npass; ++ps) {
         const int R = A.plan.radix[ps], Ns = A.plan.ns[ps], tws = A.plan.twstep[ps];
@@ -1419,7 +1451,7 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     }
 }
 template <int NT, int MAXB, int MAXP, int SPECM>
-__global__ __launch_bounds__(NT, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_fused_kernel(FusedArgs A) {
+__global__ __launch_bounds__(NT, (fused_occ<MAXB, SPECM>())) void profile_fused_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     profile_fused_row<NT, MAXB, MAXP, SPECM>(A, blockIdx.x, smem);
 }
@@ -2650,7 +2682,7 @@ __global__ __launch_bounds__(256, HMG_ROWS_OCC) void rows_group_kernel(RowsGroup
 }
 
 template <int MAXB, int MAXP, int SPECM>
-__global__ __launch_bounds__(512, (MAXB <= 2 ? HMG_FUSED_OCC : 4)) void profile_group_kernel(ChainArgs C, FusedArgs A,
+__global__ __launch_bounds__(512, (fused_occ<MAXB, SPECM>())) void profile_group_kernel(ChainArgs C, FusedArgs A,
                                                                                               int nchain) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
@@ -3004,6 +3036,7 @@ static int ctx_init(hmg_ctx* c, int device) {
     }
     if (const char* s = getenv("HMG_FUSED_FFT")) c->use_fused_fft = atoi(s);
     if (const char* s = getenv("HMG_PRUNED_FFT")) c->use_pruned_fft = atoi(s);
+    if (const char* s = getenv("HMG_FUSED_MAX_M")) c->fused_max_m = atoi(s);
     if (const char* s = getenv("HMG_PRUNED_LP_MIN")) c->pruned_lp_min = atoi(s);
     HIP_TRY(hipMalloc((void**)&c->d_fault, sizeof(int)));
     HIP_TRY(hipMemset(c->d_fault, 0, sizeof(int)));
@@ -3686,7 +3719,7 @@ static int get_fused_plan(hmg_ctx* c, int nxs, FusedPlan** out) {
     }
     FusedPlan P;
     const int M = nxs / 2;
-    bool ok = (nxs % 2 == 0) && M >= 4 && fft_make_plan(M, &P.plan) && (size_t)M * 16 <= 96 * 1024;
+    bool ok = (nxs % 2 == 0) && M >= 4 && fft_make_plan(M, &P.plan) && M <= c->fused_max_m;
     if (ok) {
         int maxb = 0;
         for (int i = 0; i < P.plan.npass; ++i) {
@@ -3923,8 +3956,15 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
                                   pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
                                   !getenv("HMG_FUSED_GENERIC");      // (testing: force the run-time plan)
             const bool grouped = C && nchain > 0 && FUSED_NT == 512;
+            // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 4000, 10000
+            const int ctM = (FUSED_NT == 512 && !getenv("HMG_FUSED_GENERIC") &&
+                             (pl.M == 500 || pl.M == 1000 || pl.M == 2000 || pl.M == 5000)) ? pl.M : 0;
             if (grouped) {
                 if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds);
+                else if (ctM == 500) rc = launch_fused_group<1, 1, 500>(c, A, rows, *C, nchain, chain_lds);
+                else if (ctM == 1000) rc = launch_fused_group<1, 1, 1000>(c, A, rows, *C, nchain, chain_lds);
+                else if (ctM == 2000) rc = launch_fused_group<2, 2, 2000>(c, A, rows, *C, nchain, chain_lds);
+                else if (ctM == 5000) rc = launch_fused_group<4, 5, 5000>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 1 && mp <= 2) rc = launch_fused_group<1, 2>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 2 && mp <= 3) rc = launch_fused_group<2, 3>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 2 && mp <= 4) rc = launch_fused_group<2, 4>(c, A, rows, *C, nchain, chain_lds);
@@ -3932,6 +3972,10 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
                 if (!rc && chain_done) *chain_done = 1;
             }
             else if (spec2500) rc = launch_fused<2, 3, 2500>(c, A, rows);                 // nxs = 5000, compile-time plan
+            else if (ctM == 500) rc = launch_fused<1, 1, 500>(c, A, rows);
+            else if (ctM == 1000) rc = launch_fused<1, 1, 1000>(c, A, rows);
+            else if (ctM == 2000) rc = launch_fused<2, 2, 2000>(c, A, rows);
+            else if (ctM == 5000) rc = launch_fused<4, 5, 5000>(c, A, rows);
             else if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
             else if (mb <= 2 && mp <= 3) rc = launch_fused<2, 3>(c, A, rows);
             else if (mb <= 2 && mp <= 4) rc = launch_fused<2, 4>(c, A, rows);
