@@ -1189,7 +1189,13 @@ template <int MAXB, int SPECM> constexpr int fused_occ() { return MAXB > 2 ? 4 :
 // SPECM != 0: the plan is known at compile time (SPECM = 2500, passes 4,5,5,5,5: nxs = 5000, the default
 // length of the Battaglia profiles) - strides, twiddle steps and the j/Ns multipliers become immediates and
 // the pass loop with its dispatch chain unrolls.
-template <int NT, int MAXB, int MAXP, int SPECM>
+// ABL: phase-ablation policy for timing experiments (tools/abl_run.sh, tools/abl_pmc.sh build the library with
+// -DHMG_ABL=N): 0 = the product (the only value a normal build instantiates); 5 workgroup launch only, 6 + row
+// scalars, 4 phase A without its transcendentals, 1 stop after phase A, 2 after phase B, 3 after phase C.
+#ifndef HMG_ABL
+#define HMG_ABL 0
+#endif
+template <int NT, int MAXB, int MAXP, int SPECM, int ABL = HMG_ABL>
 __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, double* smem) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
@@ -1198,10 +1204,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     const int M = SPECM ? SPECM : A.plan.M, nxs = SPECM ? 2 * SPECM : A.nxs;
     double* red = smem + 2 * (size_t)M;
     int* s_cnt = reinterpret_cast<int*>(red + 17);
-#if defined(HMG_ABL) && HMG_ABL == 5     // timing experiment: workgroup launch only
-    if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = 1.0;
-    return;
-#endif
+    if constexpr (ABL == 5) {     // timing experiment: workgroup launch only
+        if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = 1.0;
+        return;
+    }
     const double Aamp = A.amp ? A.amp[row] : A.amp_c;
     const double XC = A.xc ? A.xc[row] : A.xc_c;
     const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
@@ -1259,10 +1265,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
             red[23] = 1.0 / A.kts[1];
         }
     }
-#if defined(HMG_ABL) && HMG_ABL == 6     // timing experiment: launch + row scalars, no integrand
-    if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = Aamp + XC + AL + EX + cm + ln_xc;
-    return;
-#endif
+    if constexpr (ABL == 6) {     // timing experiment: launch + row scalars, no integrand
+        if (threadIdx.x == 0) A.out[(size_t)row * A.nk] = Aamp + XC + AL + EX + cm + ln_xc;
+        return;
+    }
     // ---- phase A: y_n = x_n rho(x_n) theta(x_n <= cmax) packed as (y_2p, y_2p+1); mass norm
     // Pruned first pass: the integrand is zero beyond the truncation radius (85 % of a Battaglia
     // row at xmax = 20).  When every packed sample p >= M/R0 is zero, the first radix-R0 pass
@@ -1281,13 +1287,13 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         const int j = 2 * p;
         const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
         double r0 = 0.0, r1 = 0.0;
-#if defined(HMG_ABL) && HMG_ABL == 4     // timing experiment: phase A without its transcendentals
-        if (!(fabs(xv.x) > cm)) r0 = Aamp * xv.x + AL;
-        if (!(fabs(xv.y) > cm)) r1 = Aamp * xv.y + EX;
-#else
-        if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
-        if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
-#endif
+        if constexpr (ABL == 4) {     // timing experiment: phase A without its transcendentals
+            if (!(fabs(xv.x) > cm)) r0 = Aamp * xv.x + AL;
+            if (!(fabs(xv.y) > cm)) r1 = Aamp * xv.y + EX;
+        } else {
+            if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
+            if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+        }
         const cplx y = cplx{xv.x * r0, xv.y * r1};
         if (pruned && SPECM != 2500) {
             // the R0 copies go out in an order rotated by lane/4: with t the same in every lane, lanes l and l+4
@@ -1322,10 +1328,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
     }
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
-#if defined(HMG_ABL) && (HMG_ABL == 1 || HMG_ABL == 4)     // timing experiments only: stop after phase A
-    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[0];
-    return;
-#endif
+    if constexpr (ABL == 1 || ABL == 4) {     // timing experiments only: stop after phase A
+        if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[0];
+        return;
+    }
     // ---- phase B: in-place Stockham FFT of length M
     // (Tried and dropped, MI355X: fetching all R operands before the twiddle products and requesting the
     // next pass's twiddle between the two halves of a pass.  Both lengthen live ranges under the 64-VGPR
@@ -1358,10 +1364,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         else if (R == 3) { if (one) fused_pass<NT, 3, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
         else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
     }
-#if defined(HMG_ABL) && HMG_ABL == 2     // stop after phase B
-    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[24];
-    return;
-#endif
+    if constexpr (ABL == 2) {     // stop after phase B
+        if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[24];
+        return;
+    }
     // ---- phase C: Im F_j -> u_j = -Im F_j * step / kt_j / mnorm for the reachable modes
     // j = 1..jn, into smem[0..jn-1]
     const double sc = red[24];                    // u_j = Im F_j * this / j   (kt_j = j kt_1)
@@ -1393,10 +1399,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     }
     if (threadIdx.x == 0) u[M - 1] = 0.0;  // Nyquist mode: Im F_M == 0
     __syncthreads();
-#if defined(HMG_ABL) && HMG_ABL == 3     // stop after phase C
-    if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = u[threadIdx.x];
-    return;
-#endif
+    if constexpr (ABL == 3) {     // stop after phase C
+        if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = u[threadIdx.x];
+        return;
+    }
     // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid:
     // bracket j = floor(k/k_lo), weight k/k_lo - j (one FMA), two LDS reads.  The left fill is a
     // plain splat (63 % of the Battaglia tensor at Config 3).

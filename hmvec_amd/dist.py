@@ -42,7 +42,9 @@ def rendezvous_path(tag, world):
     the launcher's PID (all ranks of one launch share it as parent) and, under an elastic
     launcher, the restart count - so a restarted group never reads its predecessor's id."""
     restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-    name = f"hmg_rdzv_{tag}_w{world}_pp{os.getppid()}_r{restart}"
+    named = os.environ.get("HMG_LAUNCH_TAG") or os.environ.get("TORCHELASTIC_RUN_ID")
+    who = "named" if named else f"pp{os.getppid()}"       # (the file NAME only has to be common to the ranks; the
+    name = f"hmg_rdzv_{tag}_w{world}_{who}_r{restart}"     # nonce inside it is what identifies the launch)
     return os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), name)
 
 
@@ -56,14 +58,24 @@ def _parent_start_ticks():
         return "0"
 
 
-def launch_nonce(tag, world):
-    """What every rank of THIS launch knows and no earlier launch could have written: tag, world size, the
-    launcher's PID and start time, the elastic restart count.  Stored in the rendezvous file in front of the
-    id and compared by the readers - a leftover of a crashed earlier launch that happens to have the same
-    name (same port, same run id, a recycled PID) is rejected by content, not by how old it looks."""
+def launch_identity(tag, world):
+    """Text that every rank of THIS launch knows and no earlier launch could have written.  A launcher that
+    names the launch says so: HMG_LAUNCH_TAG, or torchrun's TORCHELASTIC_RUN_ID (with the restart count) - these
+    hold whatever sits between the launcher and the ranks (a per-rank wrapper script gives every rank a different
+    parent).  Only when neither is set does the identity fall back on the parent process: its PID and start time."""
     restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-    text = f"{tag}|w{world}|pp{os.getppid()}@{_parent_start_ticks()}|r{restart}"
-    return text.encode()[:NONCE_BYTES].ljust(NONCE_BYTES, b"\0")
+    named = os.environ.get("HMG_LAUNCH_TAG") or os.environ.get("TORCHELASTIC_RUN_ID")
+    who = f"id:{named}" if named else f"pp{os.getppid()}@{_parent_start_ticks()}"
+    return f"{tag}|w{world}|{who}|r{restart}"
+
+
+def launch_nonce(tag, world):
+    """The launch identity as stored in the rendezvous file in front of the id and compared by the readers - a
+    leftover of a crashed earlier launch that happens to have the same name (same port, same run id, a recycled
+    PID) is rejected by content, not by how old it looks.  SHA-256 of the text (hex), so that a long tag cannot
+    push part of the identity out of the fixed-size field."""
+    import hashlib
+    return hashlib.sha256(launch_identity(tag, world).encode()).hexdigest().encode().ljust(NONCE_BYTES, b"\0")
 
 
 NONCE_BYTES = 96
@@ -94,17 +106,22 @@ def exchange_unique_id(ctx, rank, world, tag):
     # (the first library page-in on a fresh box can take minutes; a launcher that supervises its ranks sets
     # a shorter limit: bench.py)
     deadline = time.time() + float(os.environ.get("HMG_RDZV_TIMEOUT", "600"))
+    seen = None
     while time.time() < deadline:
         try:
             with open(path, "rb") as f:
                 raw = f.read()
-            if len(raw) == NONCE_BYTES + nat.COMM_ID_BYTES and raw[:NONCE_BYTES] == nonce:
-                buf.raw = raw[NONCE_BYTES:]
-                return buf
+            if len(raw) == NONCE_BYTES + nat.COMM_ID_BYTES:
+                if raw[:NONCE_BYTES] == nonce:
+                    buf.raw = raw[NONCE_BYTES:]
+                    return buf
+                seen = raw[:NONCE_BYTES]
         except FileNotFoundError:
             pass
         time.sleep(0.01)
-    raise TimeoutError(f"no RCCL unique id of this launch at {path}")
+    found = "no file" if seen is None else f"a file with nonce {seen.rstrip(bytes(1)).decode(errors='replace')[:16]}..."
+    raise TimeoutError(f"no RCCL unique id of this launch at {path}: expected nonce "
+                       f"{nonce.rstrip(bytes(1)).decode()[:16]}... (identity '{launch_identity(tag, world)}'), found {found}")
 
 
 class RcclComm:

@@ -100,3 +100,25 @@ def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
     uid = dist.exchange_unique_id(StubCtx(), 0, 2, tag)
     t.join(timeout=10)
     assert got["id"] == uid.raw == bytes(range(128))
+
+
+def test_launch_identity_survives_wrappers_and_long_tags(monkeypatch):
+    """the nonce must not depend on the parent process when the launcher names the launch (a per-rank
+    wrapper script gives every rank another parent), and a long tag must not push part of it out of the field."""
+    from hmvec_amd import dist
+    monkeypatch.delenv("HMG_LAUNCH_TAG", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    by_parent = dist.launch_nonce("29500_x", 2)
+    assert f"pp{os.getppid()}" in dist.launch_identity("29500_x", 2)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run-" + "x" * 300)
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    a = dist.launch_nonce("29500_x", 2)
+    assert "pp" not in dist.launch_identity("29500_x", 2).split("|")[2] and a != by_parent
+    assert len(a) == dist.NONCE_BYTES and a.rstrip(b"\0").isalnum()
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")          # a restarted group: another identity
+    assert dist.launch_nonce("29500_x", 2) != a
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run-" + "x" * 299 + "y")   # differs only beyond byte 96 of the text
+    assert dist.launch_nonce("29500_x", 2) != a
+    monkeypatch.setenv("HMG_LAUNCH_TAG", "mine")                    # the explicit tag wins
+    assert "id:mine" in dist.launch_identity("29500_x", 2)
