@@ -87,6 +87,10 @@ struct PrunedPlan {                       // tables of the pruned long-grid rout
     hmg::cplx* twB = nullptr;             // exp(-2 pi i t / M), t < M = nxs/2
     hmg::UnpackTw* twN = nullptr;         // unpack constants for j <= M/2
 };
+struct ChirpPlan {                        // tables of the chirp route (ldsfft.hpp: ChirpTables), per (nxs, LP, p0)
+    hmg::cplx *chP = nullptr, *chJ = nullptr, *Bw = nullptr;
+    int Jw = 0;
+};
 struct SupportKey {
     const void *cmax, *xs;
     int rows, nxs;
@@ -112,6 +116,8 @@ struct hmg_ctx {
     int use_pruned_fft = 1;                        // HMG_PRUNED_FFT=0: long grids go to rocFFT as before round 4
     int fused_max_m = 6144;                        // HMG_FUSED_MAX_M: longest packed row the one-row-in-LDS kernel takes
     int pruned_lp_min = 0;                         // HMG_PRUNED_LP_MIN: smallest sub-transform length to consider
+    int use_chirp = 1;                             // HMG_CHIRP=0: every row of a long grid takes the decomposition
+    std::map<std::tuple<int, int, int>, ChirpPlan> chirp;   // (nxs, LP, p0) -> tables
     std::map<int, PrunedPlan> pruned;              // nxs -> tables of the pruned long-grid route
     std::map<SupportKey, int> support;             // last measured support bound (packed samples) of a launch's rows
     int* d_fault = nullptr;                        // device word a kernel raises when it cannot do what it was launched for
@@ -1480,6 +1486,12 @@ struct PrunedArgs {
     double* u;            // [rows of this launch][M]: u_j at [j-1]
     int* fault;           // set when a row's support turns out longer than LP (stale support bound)
     int row0;             // first row of this launch
+    // chirp route for rows that need few modes (ldsfft.hpp; nullptr: every row takes the decomposition)
+    const cplx* chP;      // ch(p), p < LP
+    const cplx* chJ;      // ch(j), j <= Jw
+    const cplx* Bw;       // transform of the chirp window / Lc, Lc = 2 LP
+    const cplx* twC;      // exp(-2 pi i t / Lc)
+    int Jw, p0;           // modes |j| <= Jw are in the window; it was built for supports of <= p0 packed samples
 };
 
 // The passes 1 .. npass-1 of the sub-transforms (pass 0 runs from registers, profile_pruned_row).
@@ -1489,11 +1501,11 @@ struct PrunedArgs {
 #ifndef HMG_PRUNED_TWLDS
 #define HMG_PRUNED_TWLDS 0
 #endif
-template <int NT, int LP, int PS>
+template <int NT, int LP, int PS, int NBUF = 2>
 __device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* twL, int nbuf, int keep) {
     if constexpr (PS < SubPass<LP, 0>::P.npass) {
         using S = SubPass<LP, PS>;
-        constexpr int MAXB = (2 * S::nb + NT - 1) / NT;
+        constexpr int MAXB = (NBUF * S::nb + NT - 1) / NT;
         cplx v[MAXB][S::R];
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
@@ -1507,8 +1519,14 @@ __device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* twL, int nb
             if (sub_pass_active<LP, PS>(jj, nbuf, keep)) sub_pass_store<LP, PS>(buf, jj, v[b]);
         }
         __syncthreads();
-        pruned_passes<NT, LP, PS + 1>(buf, twL, nbuf, keep);
+        pruned_passes<NT, LP, PS + 1, NBUF>(buf, twL, nbuf, keep);
     }
+}
+// lengths whose chirp route is compiled in: the thread that owns the samples j, j + LP/2 of the decomposition's
+// radix-2 first pass owns exactly the two non-zero inputs of butterfly j of the radix-4 first pass at Lc = 2 LP
+template <int LP> constexpr bool chirp_ok() {
+    if constexpr (LP == 1000 || LP == 1250) return SubPass<LP, 0>::R == 2 && SubPass<2 * LP, 0>::R == 4;
+    else return false;
 }
 
 template <int NT, int LP>
@@ -1626,7 +1644,59 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     double* __restrict__ u = G.u + (size_t)(row - G.row0) * M;
     constexpr int nb_last = SubPass<LP, S0::P.npass - 1>::nb;
     const int keep = pruned_keep(R, M, nb_last, jn);
-    for (int g = 0; g <= R / 2; ++g) {
+    bool chirped = false;
+    if constexpr (chirp_ok<LP>()) {
+        // ---- rows that need few modes: the chirp route - two transforms of length 2 LP instead of R of length LP
+        // (the window was built for supports up to p0 packed samples: a row beyond it takes the decomposition)
+        if (G.Bw != nullptr && jn <= G.Jw && A.xs[2 * G.p0 < nxs ? 2 * G.p0 : nxs - 1] > cm) {
+            chirped = true;
+            constexpr int LC = 2 * LP;
+            using C0 = SubPass<LC, 0>;
+            static_assert(C0::nb == nb0 && MAXB0 == (C0::nb + NT - 1) / NT, "sample ownership");
+            constexpr int nb_last_c = SubPass<LC, C0::P.npass - 1>::nb;
+#pragma unroll
+            for (int b = 0; b < MAXB0; ++b) {
+                const int jb = threadIdx.x + b * NT;
+                if (jb < nb0) {
+                    cplx v[4];
+                    chirp_first_pass(zp[b][0], zp[b][1], G.chP[jb], G.chP[jb + nb0], v);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) buf[4 * jb + t] = v[t];
+                }
+            }
+            __syncthreads();
+            pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, -1);
+            {   // product with the window's transform, fused into the first pass of the second transform
+                cplx v[MAXB0][4];
+#pragma unroll
+                for (int b = 0; b < MAXB0; ++b) {
+                    const int jb = threadIdx.x + b * NT;
+                    if (jb < nb0) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[b][t] = cmul(buf[jb + t * nb0], G.Bw[jb + t * nb0]);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int b = 0; b < MAXB0; ++b) {
+                    const int jb = threadIdx.x + b * NT;
+                    if (jb < nb0) {
+                        dft_small<4>(v[b]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) buf[4 * jb + t] = v[b][t];
+                    }
+                }
+                __syncthreads();
+            }
+            pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, (2 * jn + 2 < nb_last_c) ? jn : -1);
+            const double sc = red[24];
+            for (int j = 1 + (int)threadIdx.x; j <= jn; j += NT) {
+                const UnpackTw w = A.twN[j];
+                u[j - 1] = chirp_unpack(buf, LC, j, G.chJ[j], w) * sc * w.rj;
+            }
+        }
+    }
+    for (int g = 0; g <= R / 2 && !chirped; ++g) {
         if (!pruned_group_needed(R, M, g, jn)) break;          // (groups are needed in ascending order of g)
         const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
 #pragma unroll
@@ -3044,6 +3114,7 @@ static int ctx_init(hmg_ctx* c, int device) {
     if (const char* s = getenv("HMG_PRUNED_FFT")) c->use_pruned_fft = atoi(s);
     if (const char* s = getenv("HMG_FUSED_MAX_M")) c->fused_max_m = atoi(s);
     if (const char* s = getenv("HMG_PRUNED_LP_MIN")) c->pruned_lp_min = atoi(s);
+    if (const char* s = getenv("HMG_CHIRP")) c->use_chirp = atoi(s);
     HIP_TRY(hipMalloc((void**)&c->d_fault, sizeof(int)));
     HIP_TRY(hipMemset(c->d_fault, 0, sizeof(int)));
     HIP_TRY(hipHostMalloc((void**)&c->h_fault, sizeof(int), hipHostMallocDefault));
@@ -3086,6 +3157,11 @@ int hmg_ctx_destroy(hmg_ctx* c) {
     for (auto& kv : c->fused) {
         if (kv.second.twM) (void)hipFree(kv.second.twM);
         if (kv.second.twN) (void)hipFree(kv.second.twN);
+    }
+    for (auto& kv : c->chirp) {
+        if (kv.second.chP) (void)hipFree(kv.second.chP);
+        if (kv.second.chJ) (void)hipFree(kv.second.chJ);
+        if (kv.second.Bw) (void)hipFree(kv.second.Bw);
     }
     for (auto& kv : c->pruned) {
         if (kv.second.twB) (void)hipFree(kv.second.twB);
@@ -3810,6 +3886,25 @@ static int get_pruned_plan(hmg_ctx* c, int nxs, PrunedPlan** out) {
     return 0;
 }
 
+static int get_chirp_plan(hmg_ctx* c, int nxs, int LP, int p0, ChirpPlan** out) {
+    const auto key = std::make_tuple(nxs, LP, p0);
+    auto it = c->chirp.find(key);
+    if (it != c->chirp.end()) { *out = &it->second; return 0; }
+    REQUIRE(!c->capturing, "chirp tables cannot be built inside a captured step: run the step once eagerly first");
+    const ChirpTables T = chirp_make_tables(nxs / 2, 2 * LP, p0);
+    ChirpPlan P;
+    P.Jw = T.Jw;
+    HIP_TRY(hipMalloc((void**)&P.chP, T.chP.size() * sizeof(cplx)));
+    HIP_TRY(hipMalloc((void**)&P.chJ, T.chJ.size() * sizeof(cplx)));
+    HIP_TRY(hipMalloc((void**)&P.Bw, T.Bw.size() * sizeof(cplx)));
+    HIP_TRY(hipMemcpy(P.chP, T.chP.data(), T.chP.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.chJ, T.chJ.data(), T.chJ.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P.Bw, T.Bw.data(), T.Bw.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    auto res = c->chirp.emplace(key, P);
+    *out = &res.first->second;
+    return 0;
+}
+
 // Support bound of a launch's rows in packed samples.  Eager calls measure it (one small kernel, a 4-byte copy);
 // inside a captured step the value of the last eager call with the same arrays is used - what a replay computes
 // is what was captured - and the kernel itself re-checks every row (fault word).
@@ -3881,6 +3976,19 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
     G.F = A0;
     G.F.twN = PP->twN;
     G.M = M; G.R = M / LP; G.twB = PP->twB; G.twL = FL->twM; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
+    G.chP = G.chJ = G.Bw = G.twC = nullptr;
+    G.Jw = 0; G.p0 = 0;
+    if (c->use_chirp && (LP == 1000 || LP == 1250) && p0max >= 1) {
+        // the window is built for the support bound rounded up to 16 samples (fewer distinct tables; Jw shrinks by <= 8)
+        int p0 = (p0max + 15) / 16 * 16;
+        if (p0 > LP) p0 = LP;
+        ChirpPlan* CP = nullptr;
+        FusedPlan* FC = nullptr;
+        if (get_chirp_plan(c, nxs, LP, p0, &CP)) return 1;
+        if (get_fused_plan(c, 4 * LP, &FC)) return 1;
+        REQUIRE(FC != nullptr, "no twiddle table for the chirp transform length");
+        G.chP = CP->chP; G.chJ = CP->chJ; G.Bw = CP->Bw; G.twC = FC->twM; G.Jw = CP->Jw; G.p0 = p0;
+    }
     int rc = 1, stop = -1;
     if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
     switch (LP) {

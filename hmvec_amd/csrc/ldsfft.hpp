@@ -11,6 +11,7 @@
 // against numpy.
 #pragma once
 
+#include <vector>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HMG_HD __host__ __device__ __forceinline__
@@ -350,6 +351,80 @@ HMG_HD int pruned_keep(int R, int M, int nb_last, int jn) {
     if (jn >= M - M / 2) return -1;
     const int keep = jn / R + 2;
     return 2 * keep + 2 < nb_last ? keep : -1;
+}
+
+// ---- Rows that need FEW modes of a long grid: the chirp transform.  The pruned decomposition above costs R
+// transforms of length LP whatever the row needs; most rows of a halo-model grid need a few hundred of the M modes
+// (jn = max(ks)/k_lo + 3; median 394 of 15000 on the Config-3 grid at xmax = 50).  With j p = (j^2 + p^2 - (j-p)^2)/2,
+//     Z[j] = ch(j) sum_{p < P0} (z_p ch(p)) conj(ch(j - p)),      ch(n) = exp(-i pi n^2 / M),
+// a linear convolution of the P0 chirped samples with the chirp, i.e. ONE forward transform of length
+// Lc >= P0 + 2 Jw, a pointwise product with the (tabulated) transform of the chirp window and one more transform:
+// every mode |j| <= Jw = (Lc - P0)/2 at the cost of two length-Lc transforms instead of R length-LP ones.
+// The chirp window is laid out circularly - g(n) = conj(ch(n)) at index n for 0 <= n <= Jw and at Lc + n for
+// -(Jw + P0 - 1) <= n < 0 - so that c_j lands at index j mod Lc; with the inverse transform taken as a forward one
+// read backwards (IFFT(X)[i] = FFT(X)[(Lc - i) mod Lc] / Lc), Z[j] = ch(j) Y[Lc - j] and Z[-j] = ch(j) Y[j]:
+// the needed outputs sit at the two ends of Y, where the last pass's pruning (keep) applies.
+// chirp angles are reduced exactly in integers (n^2 mod 2M) before any floating point.
+struct ChirpTables {
+    int M = 0, Lc = 0, P0 = 0, Jw = 0;
+    std::vector<cplx> chP;    // ch(p), p < Lc/2 (the samples a thread can own; zero-support entries are harmless)
+    std::vector<cplx> chJ;    // ch(j), 0 <= j <= Jw
+    std::vector<cplx> Bw;     // FFT_Lc(chirp window) / Lc
+};
+inline cplx chirp_value(long long n, int M) {
+    const long long r = (n * n) % (2LL * M);
+    const long double ang = 3.14159265358979323846264338327950288L * (long double)r / (long double)M;
+    return cplx{(double)cosl(ang), (double)-sinl(ang)};
+}
+inline ChirpTables chirp_make_tables(int M, int Lc, int P0) {
+    ChirpTables T;
+    T.M = M; T.Lc = Lc; T.P0 = P0;
+    T.Jw = (Lc - P0) / 2;
+    if (T.Jw > M / 2 - 1) T.Jw = M / 2 - 1;
+    T.chP.resize(Lc / 2);
+    for (int p = 0; p < Lc / 2; ++p) T.chP[p] = chirp_value(p, M);
+    T.chJ.resize(T.Jw + 1);
+    for (int j = 0; j <= T.Jw; ++j) T.chJ[j] = chirp_value(j, M);
+    // the window in long double, its transform by the defining sum (once per (M, Lc, P0): ~Lc^2 products)
+    std::vector<long double> br(Lc, 0.0L), bi(Lc, 0.0L), twr(Lc), twi(Lc);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    auto g = [&](long long n, long double& re, long double& im) {
+        const long long r = (n * n) % (2LL * M);
+        const long double ang = pi * (long double)r / (long double)M;
+        re = cosl(ang); im = sinl(ang);                    // conj(ch(n))
+    };
+    for (int n = 0; n <= T.Jw; ++n) g(n, br[n], bi[n]);
+    for (int n = 1; n <= T.Jw + P0 - 1; ++n) g(-n, br[Lc - n], bi[Lc - n]);
+    for (int t = 0; t < Lc; ++t) { twr[t] = cosl(2 * pi * t / Lc); twi[t] = -sinl(2 * pi * t / Lc); }
+    T.Bw.resize(Lc);
+    for (int k = 0; k < Lc; ++k) {
+        long double sr = 0.0L, si = 0.0L;
+        long long idx = 0;
+        for (int m = 0; m < Lc; ++m) {
+            sr += br[m] * twr[idx] - bi[m] * twi[idx];
+            si += br[m] * twi[idx] + bi[m] * twr[idx];
+            idx += k;
+            if (idx >= Lc) idx -= Lc;
+        }
+        T.Bw[k] = cplx{(double)(sr / Lc), (double)(si / Lc)};
+    }
+    return T;
+}
+// first pass (radix 4, sub-transform size 1) of the forward transform of the chirped row: the thread owns samples
+// p = j and j + Lc/4 (the row is zero from Lc/2 on), i.e. inputs (a0, a1, 0, 0) of butterfly j
+HMG_HD void chirp_first_pass(cplx z0, cplx z1, cplx c0, cplx c1, cplx* v) {
+    const cplx a0 = cmul(z0, c0), a1 = cmul(z1, c1);
+    v[0] = cadd(a0, a1);
+    v[1] = cadd(a0, cmul_mi(a1));
+    v[2] = csub(a0, a1);
+    v[3] = csub(a0, cmul_mi(a1));
+}
+// mode j (1 <= j <= Jw) from the transformed product Y: Z[j] = ch(j) Y[Lc - j], Z[M - j] = Z[-j] = ch(j) Y[j]
+HMG_HD double chirp_unpack(const cplx* Y, int Lc, int j, cplx chj, const UnpackTw& w) {
+    const cplx zj = cmul(chj, Y[Lc - j]), zmj = cmul(chj, Y[j]);
+    double fa, fb;
+    unpack_imag_pair(zj, zmj, w.co, w.si, fa, fb);
+    return fa;
 }
 
 }  // namespace hmg

@@ -175,3 +175,77 @@ extern "C" int ldsfft_pruned_rfft_imag(const double* y, int n, int LP, int nthre
         default: return 3;
     }
 }
+
+// The chirp route of the long-grid kernel (ldsfft.hpp, "Rows that need FEW modes"), sequenced as profile_pruned_row
+// sequences it for a row with jn <= Jw: first pass of the chirped row from the samples a thread owns, the other
+// passes of the length-Lc plan, the product with the tabulated chirp-window transform fused into the first pass of
+// the second transform, its other passes (last one pruned), unpack.  Lc = 2 LP.
+template <int LC, int PS>
+static void run_single_passes(std::vector<cplx>& buf, const std::vector<cplx>& tw, int keep, int nthreads) {
+    if constexpr (PS < SubPass<LC, 0>::P.npass) {
+        using S = SubPass<LC, PS>;
+        const int maxb = (S::nb + nthreads - 1) / nthreads;
+        std::vector<cplx> regs((size_t)nthreads * maxb * S::R);
+        for (int tid = 0; tid < nthreads; ++tid)
+            for (int b = 0; b < maxb; ++b) {
+                const int jj = tid + b * nthreads;
+                if (sub_pass_active<LC, PS>(jj, 1, keep)) sub_pass_load<LC, PS>(buf.data(), tw.data(), jj, &regs[((size_t)tid * maxb + b) * S::R]);
+            }
+        for (int tid = 0; tid < nthreads; ++tid)
+            for (int b = 0; b < maxb; ++b) {
+                const int jj = tid + b * nthreads;
+                if (sub_pass_active<LC, PS>(jj, 1, keep)) sub_pass_store<LC, PS>(buf.data(), jj, &regs[((size_t)tid * maxb + b) * S::R]);
+            }
+        run_single_passes<LC, PS + 1>(buf, tw, keep, nthreads);
+    }
+}
+template <int LP>
+static int chirp_rfft_imag(const double* y, int n, int p0, int nthreads, int jn, double* imF) {
+    constexpr int LC = 2 * LP;
+    using C0 = SubPass<LC, 0>;
+    static_assert(C0::R == 4 && C0::Ns == 1, "first pass of the chirp transforms is radix 4");
+    const int M = n / 2;
+    if (n % 2 || p0 > LP) return 2;
+    for (int i = 2 * p0; i < n; ++i)
+        if (y[i] != 0.0) return 4;
+    const ChirpTables T = chirp_make_tables(M, LC, p0);
+    if (jn > T.Jw) return 5;
+    const long double twopi = 6.283185307179586476925286766559L;
+    std::vector<cplx> tw(LC), buf(LC, cplx{1.0e30, -1.0e30});
+    for (int t = 0; t < LC; ++t) tw[t] = {(double)cosl(twopi * t / LC), (double)-sinl(twopi * t / LC)};
+    constexpr int nb0 = C0::nb;                          // = LP / 2
+    for (int jb = 0; jb < nb0; ++jb) {
+        cplx v[4];
+        const cplx z0 = {y[2 * jb], y[2 * jb + 1]}, z1 = {y[2 * (jb + nb0)], y[2 * (jb + nb0) + 1]};
+        chirp_first_pass(z0, z1, T.chP[jb], T.chP[jb + nb0], v);
+        for (int t = 0; t < 4; ++t) buf[4 * jb + t] = v[t];
+    }
+    run_single_passes<LC, 1>(buf, tw, -1, nthreads);
+    {
+        std::vector<cplx> regs((size_t)nb0 * 4);
+        for (int jb = 0; jb < nb0; ++jb)
+            for (int t = 0; t < 4; ++t) regs[4 * jb + t] = cmul(buf[jb + t * nb0], T.Bw[jb + t * nb0]);
+        for (int jb = 0; jb < nb0; ++jb) {
+            dft_small<4>(&regs[4 * jb]);
+            for (int t = 0; t < 4; ++t) buf[4 * jb + t] = regs[4 * jb + t];
+        }
+    }
+    constexpr int nb_last = SubPass<LC, C0::P.npass - 1>::nb;
+    run_single_passes<LC, 1>(buf, tw, (2 * jn + 2 < nb_last) ? jn : -1, nthreads);
+    for (int j = 0; j <= M; ++j) imF[j] = NAN;
+    for (int j = 1; j <= jn; ++j) {
+        const long double th = twopi * j / n;
+        const UnpackTw w{(double)cosl(th), (double)sinl(th), 1.0 / j, 1.0 / (M - j)};
+        imF[j] = chirp_unpack(buf.data(), LC, j, T.chJ[j], w);
+    }
+    imF[0] = 0.0;
+    return 0;
+}
+extern "C" int ldsfft_chirp_rfft_imag(const double* y, int n, int LP, int p0, int nthreads, int jn, double* imF) {
+    switch (LP) {
+        case 1000: return chirp_rfft_imag<1000>(y, n, p0, nthreads, jn, imF);
+        case 1250: return chirp_rfft_imag<1250>(y, n, p0, nthreads, jn, imF);
+        default: return 3;
+    }
+}
+extern "C" int ldsfft_chirp_window(int n, int LP, int p0) { return chirp_make_tables(n / 2, 2 * LP, p0).Jw; }

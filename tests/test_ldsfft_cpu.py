@@ -24,6 +24,9 @@ def lib(tmp_path_factory):
     lib.ldsfft_pruned_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p]
     lib.ldsfft_pruned_rfft_imag.restype = ctypes.c_int
+    lib.ldsfft_chirp_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_void_p]
+    lib.ldsfft_chirp_rfft_imag.restype = ctypes.c_int
     return lib
 
 
@@ -98,3 +101,33 @@ def test_pruned_decomposition_rejects_what_it_cannot_take(lib):
     out = np.zeros(15001)
     assert lib.ldsfft_pruned_rfft_imag(y.ctypes.data, 30000, 1000, 512, 100, out.ctypes.data) == 4    # support too long
     assert lib.ldsfft_pruned_rfft_imag(y.ctypes.data, 30000, 2000, 512, 100, out.ctypes.data) == 2    # LP does not divide M
+
+
+@pytest.mark.parametrize("n,LP,p0,nonzero,jn", [
+    (30000, 1000, 820, 1639, 394), (30000, 1000, 820, 1640, 590), (30000, 1000, 820, 100, 1), (30000, 1000, 1000, 2000, 500),
+    (30000, 1000, 700, 1399, 650), (40000, 1250, 1200, 2400, 650), (40000, 1250, 1250, 2500, 625), (40000, 1250, 900, 1777, 0),
+    (10000, 1000, 683, 1366, 658)])
+def test_chirp_route_matches_numpy(lib, n, LP, p0, nonzero, jn):
+    """Rows that need few modes: the chirp transform (two length-2LP transforms) gives every mode j <= jn <= Jw of a
+    row that is zero from packed sample p0 on - numpy's rfft to rounding (relative to the largest mode)."""
+    rng = np.random.default_rng(n + LP + p0 + jn)
+    y = np.zeros(n)
+    y[:nonzero] = rng.standard_normal(nonzero) * np.exp(-np.linspace(0, 3, nonzero))
+    M = n // 2
+    out = np.zeros(M + 1)
+    assert jn <= lib.ldsfft_chirp_window(n, LP, p0)
+    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, n, LP, p0, 512, jn, out.ctypes.data) == 0
+    ref = np.fft.rfft(y)
+    scale = np.max(np.abs(ref))
+    need = np.arange(1, jn + 1)
+    assert need.size == 0 or np.max(np.abs(out[need] - ref.imag[need])) < 1e-14 * scale * np.log2(n)
+
+
+def test_chirp_route_refuses_modes_outside_its_window(lib):
+    y = np.zeros(30000)
+    y[:1600] = 1.0
+    out = np.zeros(15001)
+    jw = lib.ldsfft_chirp_window(30000, 1000, 820)
+    assert jw == 590
+    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 820, 512, jw + 1, out.ctypes.data) == 5
+    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 700, 512, 10, out.ctypes.data) == 4    # support > p0
