@@ -310,6 +310,59 @@ def readme_config2(ctx, with_cpu=True):
 
 
 # ------------------------------------------------------------------------------------------------
+# the radial grid the reference's own callers use (examples/lensing_baryons.py:27, bin/tests.py:308)
+# ------------------------------------------------------------------------------------------------
+def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
+    """add_battaglia_profile(xmax=50, nxs=30000) on the bench grid: milliseconds of the profile stage (HIP events)
+    through the pruned long-grid route (+ chirp route for rows that need few modes) and through the chunked rocFFT
+    route it replaces, the agreement of the two tensors, and the wall time of whole passes with that profile."""
+    import hmvec_amd as hm
+    from hmvec_amd import _native as nat
+    out = {"profile": "add_battaglia_profile('electron', family='AGN', xmax=50, nxs=30000)",
+           "grid": f"zs={zs.size} ms={ms.size} ks={ks.size}"}
+    tens = {}
+    for route, env in (("pruned", {}), ("pruned_no_chirp", {"HMG_CHIRP": "0"}), ("rocfft", {"HMG_PRUNED_FFT": "0"})):
+        for k_, v_ in env.items():
+            os.environ[k_] = v_
+        try:
+            c2 = nat.Context(ctx.device)          # the route switches are read when a context is created
+            h2 = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic", ctx=c2)
+            n = reps if route != "rocfft" else 3
+
+            def one(timed):
+                h2.init_mass_function(ms)
+                h2.add_nfw_profile("nfw", ignore_existing=True)
+                if timed:
+                    c2.call("hmg_bracket_next", nat.KERNEL_PROFILE_FFT, 44, 45)
+                h2.add_battaglia_profile("electron", family="AGN", xmax=50, nxs=30000, ignore_existing=True)
+                h2.add_hod("g", mthresh=mthr, ignore_existing=True)
+                return h2.power_device_batch(pairs)
+            one(False); one(False)
+            c2.sync()
+            t_fft = []
+            t0 = time.perf_counter()
+            for _ in range(n):
+                one(True)
+                c2.sync()
+                t_fft.append(c2.elapsed_ms(44, 45))
+            wall = (time.perf_counter() - t0) / n * 1e3
+            out[route] = {"profile_stage_ms": float(np.median(t_fft)), "pass_wall_ms_eager": wall}
+            if route != "pruned_no_chirp":
+                tens[route] = h2.uk_profiles["electron"][::4, ::16]      # a strided sample of the (nz,nm,nk) tensor
+            del h2
+            c2.close()
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+    out["max_abs_du_between_routes"] = float(np.max(np.abs(tens["pruned"] - tens["rocfft"])))
+    out["note"] = ("pass_wall_ms_eager: one pass = mass function + NFW + this profile + HOD + the batched spectra, eager "
+                   "launches, host-synchronised after every pass (the headline ms_per_step is a HIP-graph replay); "
+                   "tolerance on u is 1e-12 absolute (tests/test_gpu_longgrid.py holds both routes to the reference's "
+                   "own fixture case_f)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # byte and instruction models of the three large kernels
 # ------------------------------------------------------------------------------------------------
 def load_profile(name):
@@ -354,6 +407,8 @@ def main():
     ap.add_argument("--lanes", action="store_true",
                     help="independent stages on separate HIP streams (concurrent graph branches)")
     ap.add_argument("--per-pair", action="store_true", help="six hmg_power launches instead of one hmg_power_batch")
+    ap.add_argument("--no-long-grid", action="store_true",
+                    help="skip the long-radial-grid block (nxs=30000, xmax=50 on the bench grid, both routes)")
     ap.add_argument("--no-readme", action="store_true",
                     help="skip the BASELINE configs[0]/[1] block (README sequence on 20 x 200 x 1001)")
     ap.add_argument("--no-limber", action="store_true",
@@ -780,6 +835,8 @@ def main():
                                     np.mean(np.array(stage_ms), axis=0).tolist()))
     if world == 1 and not args.no_readme:
         out["readme_config2"] = readme_config2(ctx, with_cpu=not args.no_cpu_baseline)
+    if world == 1 and not args.no_long_grid and (args.nxs, args.xmax) == (5000, 20.0):
+        out["long_grid"] = long_grid_block(ctx, zs, ms, ks, mthr, PAIRS)
     if pcie is not None:
         out["pcie"] = pcie
     if limber is not None:

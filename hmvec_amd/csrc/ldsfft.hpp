@@ -365,48 +365,81 @@ HMG_HD int pruned_keep(int R, int M, int nb_last, int jn) {
 // read backwards (IFFT(X)[i] = FFT(X)[(Lc - i) mod Lc] / Lc), Z[j] = ch(j) Y[Lc - j] and Z[-j] = ch(j) Y[j]:
 // the needed outputs sit at the two ends of Y, where the last pass's pruning (keep) applies.
 // chirp angles are reduced exactly in integers (n^2 mod 2M) before any floating point.
+// Rows beyond the central window take up to `nwin` further PAIRS of one-sided windows of Kp = Lc - P0 + 1 modes each,
+//     + window w: j in [j0, j0 + Kp),  j0 = Jw + 1 + (w-1) Kp,  window g(j0 - (P0-1) + m):  Z[j]  = ch(j) Y+[Kp - (j - j0)]
+//     - window w: the mirrored modes -j,                  window g(j0 + Kp - 1 + P0 - 1 - m): Z[-j] = ch(j) Y-[1 + (j - j0)]
+// (g is even).  Each costs one more length-Lc transform of the SAME forward transform A times another tabulated window
+// transform, so a row that needs jn <= Jw + nwin Kp modes costs 2 + 2 ceil((jn - Jw)/Kp) transforms.
 struct ChirpTables {
-    int M = 0, Lc = 0, P0 = 0, Jw = 0;
+    int M = 0, Lc = 0, P0 = 0, Jw = 0, Kp = 0, nwin = 0;
     std::vector<cplx> chP;    // ch(p), p < Lc/2 (the samples a thread can own; zero-support entries are harmless)
-    std::vector<cplx> chJ;    // ch(j), 0 <= j <= Jw
-    std::vector<cplx> Bw;     // FFT_Lc(chirp window) / Lc
+    std::vector<cplx> chJ;    // ch(j), 0 <= j <= Jw + nwin Kp
+    std::vector<cplx> Bw;     // FFT_Lc(chirp window) / Lc: central window, then (+1, -1, +2, -2, ...), Lc entries each
 };
 inline cplx chirp_value(long long n, int M) {
     const long long r = (n * n) % (2LL * M);
     const long double ang = 3.14159265358979323846264338327950288L * (long double)r / (long double)M;
     return cplx{(double)cosl(ang), (double)-sinl(ang)};
 }
-inline ChirpTables chirp_make_tables(int M, int Lc, int P0) {
+// forward DFT in long double, recursive by the smallest prime factor (table plans only: a few per context)
+struct ldc { long double re, im; };
+inline void ld_dft(const ldc* x, int n, int stride, ldc* out, const ldc* tw, int N) {
+    if (n == 1) { out[0] = x[0]; return; }
+    int p = 2;
+    while (n % p) ++p;
+    const int m = n / p;
+    std::vector<ldc> sub((size_t)n);
+    for (int r = 0; r < p; ++r) ld_dft(x + (size_t)r * stride, m, stride * p, sub.data() + (size_t)r * m, tw, N);
+    const int step = N / n;                              // W_n = tw[step]
+    for (int q = 0; q < p; ++q)
+        for (int k = 0; k < m; ++k) {
+            long double sr = 0.0L, si = 0.0L;
+            const long long kk = (long long)k + (long long)q * m;
+            for (int r = 0; r < p; ++r) {
+                const ldc w = tw[(size_t)((r * kk) % n) * step];
+                const ldc y = sub[(size_t)r * m + k];
+                sr += y.re * w.re - y.im * w.im;
+                si += y.re * w.im + y.im * w.re;
+            }
+            out[kk] = ldc{sr, si};
+        }
+}
+inline ChirpTables chirp_make_tables(int M, int Lc, int P0, int nwin = 0) {
     ChirpTables T;
     T.M = M; T.Lc = Lc; T.P0 = P0;
     T.Jw = (Lc - P0) / 2;
+    T.Kp = Lc - P0 + 1;
     if (T.Jw > M / 2 - 1) T.Jw = M / 2 - 1;
+    while (nwin > 0 && T.Jw + nwin * T.Kp > M / 2 - 1) --nwin;      // mirrors are never needed on this route
+    T.nwin = nwin;
     T.chP.resize(Lc / 2);
     for (int p = 0; p < Lc / 2; ++p) T.chP[p] = chirp_value(p, M);
-    T.chJ.resize(T.Jw + 1);
-    for (int j = 0; j <= T.Jw; ++j) T.chJ[j] = chirp_value(j, M);
-    // the window in long double, its transform by the defining sum (once per (M, Lc, P0): ~Lc^2 products)
-    std::vector<long double> br(Lc, 0.0L), bi(Lc, 0.0L), twr(Lc), twi(Lc);
+    const int jmax = T.Jw + nwin * T.Kp;
+    T.chJ.resize(jmax + 1);
+    for (int j = 0; j <= jmax; ++j) T.chJ[j] = chirp_value(j, M);
     const long double pi = 3.14159265358979323846264338327950288L;
-    auto g = [&](long long n, long double& re, long double& im) {
+    std::vector<ldc> tw((size_t)Lc), b((size_t)Lc), B((size_t)Lc);
+    for (int t = 0; t < Lc; ++t) tw[t] = ldc{cosl(2 * pi * t / Lc), -sinl(2 * pi * t / Lc)};
+    auto g = [&](long long n) {                          // conj(ch(n)), angle reduced in integers
         const long long r = (n * n) % (2LL * M);
         const long double ang = pi * (long double)r / (long double)M;
-        re = cosl(ang); im = sinl(ang);                    // conj(ch(n))
+        return ldc{cosl(ang), sinl(ang)};
     };
-    for (int n = 0; n <= T.Jw; ++n) g(n, br[n], bi[n]);
-    for (int n = 1; n <= T.Jw + P0 - 1; ++n) g(-n, br[Lc - n], bi[Lc - n]);
-    for (int t = 0; t < Lc; ++t) { twr[t] = cosl(2 * pi * t / Lc); twi[t] = -sinl(2 * pi * t / Lc); }
-    T.Bw.resize(Lc);
-    for (int k = 0; k < Lc; ++k) {
-        long double sr = 0.0L, si = 0.0L;
-        long long idx = 0;
-        for (int m = 0; m < Lc; ++m) {
-            sr += br[m] * twr[idx] - bi[m] * twi[idx];
-            si += br[m] * twi[idx] + bi[m] * twr[idx];
-            idx += k;
-            if (idx >= Lc) idx -= Lc;
-        }
-        T.Bw[k] = cplx{(double)(sr / Lc), (double)(si / Lc)};
+    auto emit = [&]() {
+        ld_dft(b.data(), Lc, 1, B.data(), tw.data(), Lc);
+        for (int k = 0; k < Lc; ++k) T.Bw.push_back(cplx{(double)(B[k].re / Lc), (double)(B[k].im / Lc)});
+    };
+    // central window, laid out circularly: g(n) at n for 0 <= n <= Jw, at Lc + n for -(Jw + P0 - 1) <= n < 0
+    for (int m = 0; m < Lc; ++m) b[m] = ldc{0.0L, 0.0L};
+    for (int n = 0; n <= T.Jw; ++n) b[n] = g(n);
+    for (int n = 1; n <= T.Jw + P0 - 1; ++n) b[Lc - n] = g(-n);
+    emit();
+    for (int w = 1; w <= nwin; ++w) {
+        const long long j0 = T.Jw + 1 + (long long)(w - 1) * T.Kp;
+        for (int m = 0; m < Lc; ++m) b[m] = g(j0 - (P0 - 1) + m);
+        emit();
+        for (int m = 0; m < Lc; ++m) b[m] = g(j0 + T.Kp - 1 + (P0 - 1) - m);
+        emit();
     }
     return T;
 }
@@ -419,6 +452,9 @@ HMG_HD void chirp_first_pass(cplx z0, cplx z1, cplx c0, cplx c1, cplx* v) {
     v[2] = csub(a0, a1);
     v[3] = csub(a0, cmul_mi(a1));
 }
+// one-sided windows: Z[j] from the + transform, Z[-j] from the - transform (j0 <= j < j0 + Kp)
+HMG_HD cplx chirp_plus(const cplx* Y, int Kp, int j0, int j, cplx chj) { return cmul(chj, Y[Kp - (j - j0)]); }
+HMG_HD cplx chirp_minus(const cplx* Y, int j0, int j, cplx chj) { return cmul(chj, Y[1 + (j - j0)]); }
 // mode j (1 <= j <= Jw) from the transformed product Y: Z[j] = ch(j) Y[Lc - j], Z[M - j] = Z[-j] = ch(j) Y[j]
 HMG_HD double chirp_unpack(const cplx* Y, int Lc, int j, cplx chj, const UnpackTw& w) {
     const cplx zj = cmul(chj, Y[Lc - j]), zmj = cmul(chj, Y[j]);

@@ -1,6 +1,7 @@
 // Host harness for hmvec_amd/csrc/ldsfft.hpp: runs the workgroup FFT "thread by thread" on the
 // CPU exactly as the fused GPU kernel sequences it (all loads of a pass, barrier, all stores).
 // Built by tests/test_ldsfft_cpu.py with g++; not part of the product.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 #include "../../hmvec_amd/csrc/ldsfft.hpp"
@@ -200,7 +201,7 @@ static void run_single_passes(std::vector<cplx>& buf, const std::vector<cplx>& t
     }
 }
 template <int LP>
-static int chirp_rfft_imag(const double* y, int n, int p0, int nthreads, int jn, double* imF) {
+static int chirp_rfft_imag(const double* y, int n, int p0, int nwin, int nthreads, int jn, double* imF) {
     constexpr int LC = 2 * LP;
     using C0 = SubPass<LC, 0>;
     static_assert(C0::R == 4 && C0::Ns == 1, "first pass of the chirp transforms is radix 4");
@@ -208,12 +209,13 @@ static int chirp_rfft_imag(const double* y, int n, int p0, int nthreads, int jn,
     if (n % 2 || p0 > LP) return 2;
     for (int i = 2 * p0; i < n; ++i)
         if (y[i] != 0.0) return 4;
-    const ChirpTables T = chirp_make_tables(M, LC, p0);
-    if (jn > T.Jw) return 5;
+    const ChirpTables T = chirp_make_tables(M, LC, p0, nwin);
+    if (jn > T.Jw + T.nwin * T.Kp) return 5;
     const long double twopi = 6.283185307179586476925286766559L;
     std::vector<cplx> tw(LC), buf(LC, cplx{1.0e30, -1.0e30});
     for (int t = 0; t < LC; ++t) tw[t] = {(double)cosl(twopi * t / LC), (double)-sinl(twopi * t / LC)};
     constexpr int nb0 = C0::nb;                          // = LP / 2
+    constexpr int nb_last = SubPass<LC, C0::P.npass - 1>::nb;
     for (int jb = 0; jb < nb0; ++jb) {
         cplx v[4];
         const cplx z0 = {y[2 * jb], y[2 * jb + 1]}, z1 = {y[2 * (jb + nb0)], y[2 * (jb + nb0) + 1]};
@@ -221,31 +223,50 @@ static int chirp_rfft_imag(const double* y, int n, int p0, int nthreads, int jn,
         for (int t = 0; t < 4; ++t) buf[4 * jb + t] = v[t];
     }
     run_single_passes<LC, 1>(buf, tw, -1, nthreads);
-    {
+    const std::vector<cplx> A = buf;                     // the forward transform: every window multiplies it again
+    auto second = [&](const cplx* Bw, int keep) {
         std::vector<cplx> regs((size_t)nb0 * 4);
         for (int jb = 0; jb < nb0; ++jb)
-            for (int t = 0; t < 4; ++t) regs[4 * jb + t] = cmul(buf[jb + t * nb0], T.Bw[jb + t * nb0]);
+            for (int t = 0; t < 4; ++t) regs[4 * jb + t] = cmul(A[jb + t * nb0], Bw[jb + t * nb0]);
         for (int jb = 0; jb < nb0; ++jb) {
             dft_small<4>(&regs[4 * jb]);
             for (int t = 0; t < 4; ++t) buf[4 * jb + t] = regs[4 * jb + t];
         }
-    }
-    constexpr int nb_last = SubPass<LC, C0::P.npass - 1>::nb;
-    run_single_passes<LC, 1>(buf, tw, (2 * jn + 2 < nb_last) ? jn : -1, nthreads);
-    for (int j = 0; j <= M; ++j) imF[j] = NAN;
-    for (int j = 1; j <= jn; ++j) {
+        run_single_passes<LC, 1>(buf, tw, keep, nthreads);
+    };
+    auto unpack = [&](int j, cplx zj, cplx zmj) {
         const long double th = twopi * j / n;
-        const UnpackTw w{(double)cosl(th), (double)sinl(th), 1.0 / j, 1.0 / (M - j)};
-        imF[j] = chirp_unpack(buf.data(), LC, j, T.chJ[j], w);
+        double fa, fb;
+        unpack_imag_pair(zj, zmj, (double)cosl(th), (double)sinl(th), fa, fb);
+        imF[j] = fa;
+    };
+    for (int j = 0; j <= M; ++j) imF[j] = NAN;
+    const int jc = jn < T.Jw ? jn : T.Jw;
+    second(T.Bw.data(), (2 * jc + 2 < nb_last) ? jc : -1);
+    for (int j = 1; j <= jc; ++j) {
+        const UnpackTw w{0.0, 0.0, 1.0 / j, 1.0 / (M - j)};
+        (void)w;
+        unpack(j, cmul(T.chJ[j], buf[LC - j]), cmul(T.chJ[j], buf[j]));
+    }
+    std::vector<cplx> stash(T.Kp);
+    for (int w = 1; w <= T.nwin && T.Jw + 1 + (w - 1) * T.Kp <= jn; ++w) {
+        const int j0 = T.Jw + 1 + (w - 1) * T.Kp, j1 = std::min(jn, j0 + T.Kp - 1);
+        second(T.Bw.data() + (size_t)(2 * w - 1) * LC, -1);
+        for (int j = j0; j <= j1; ++j) stash[j - j0] = chirp_plus(buf.data(), T.Kp, j0, j, T.chJ[j]);
+        second(T.Bw.data() + (size_t)(2 * w) * LC, -1);
+        for (int j = j0; j <= j1; ++j) unpack(j, stash[j - j0], chirp_minus(buf.data(), j0, j, T.chJ[j]));
     }
     imF[0] = 0.0;
     return 0;
 }
-extern "C" int ldsfft_chirp_rfft_imag(const double* y, int n, int LP, int p0, int nthreads, int jn, double* imF) {
+extern "C" int ldsfft_chirp_rfft_imag(const double* y, int n, int LP, int p0, int nwin, int nthreads, int jn, double* imF) {
     switch (LP) {
-        case 1000: return chirp_rfft_imag<1000>(y, n, p0, nthreads, jn, imF);
-        case 1250: return chirp_rfft_imag<1250>(y, n, p0, nthreads, jn, imF);
+        case 1000: return chirp_rfft_imag<1000>(y, n, p0, nwin, nthreads, jn, imF);
+        case 1250: return chirp_rfft_imag<1250>(y, n, p0, nwin, nthreads, jn, imF);
         default: return 3;
     }
 }
-extern "C" int ldsfft_chirp_window(int n, int LP, int p0) { return chirp_make_tables(n / 2, 2 * LP, p0).Jw; }
+extern "C" int ldsfft_chirp_window(int n, int LP, int p0, int nwin) {
+    const ChirpTables T = chirp_make_tables(n / 2, 2 * LP, p0, nwin);
+    return T.Jw + T.nwin * T.Kp;
+}

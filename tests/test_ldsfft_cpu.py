@@ -25,7 +25,7 @@ def lib(tmp_path_factory):
                                             ctypes.c_void_p]
     lib.ldsfft_pruned_rfft_imag.restype = ctypes.c_int
     lib.ldsfft_chirp_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                           ctypes.c_int, ctypes.c_void_p]
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.ldsfft_chirp_rfft_imag.restype = ctypes.c_int
     return lib
 
@@ -103,20 +103,24 @@ def test_pruned_decomposition_rejects_what_it_cannot_take(lib):
     assert lib.ldsfft_pruned_rfft_imag(y.ctypes.data, 30000, 2000, 512, 100, out.ctypes.data) == 2    # LP does not divide M
 
 
-@pytest.mark.parametrize("n,LP,p0,nonzero,jn", [
-    (30000, 1000, 820, 1639, 394), (30000, 1000, 820, 1640, 590), (30000, 1000, 820, 100, 1), (30000, 1000, 1000, 2000, 500),
-    (30000, 1000, 700, 1399, 650), (40000, 1250, 1200, 2400, 650), (40000, 1250, 1250, 2500, 625), (40000, 1250, 900, 1777, 0),
-    (10000, 1000, 683, 1366, 658)])
-def test_chirp_route_matches_numpy(lib, n, LP, p0, nonzero, jn):
-    """Rows that need few modes: the chirp transform (two length-2LP transforms) gives every mode j <= jn <= Jw of a
-    row that is zero from packed sample p0 on - numpy's rfft to rounding (relative to the largest mode)."""
+@pytest.mark.parametrize("n,LP,p0,nonzero,nwin,jn", [
+    (30000, 1000, 820, 1639, 0, 394), (30000, 1000, 820, 1640, 0, 590), (30000, 1000, 820, 100, 0, 1),
+    (30000, 1000, 1000, 2000, 0, 500), (30000, 1000, 700, 1399, 0, 650), (40000, 1250, 1200, 2400, 0, 650),
+    (40000, 1250, 1250, 2500, 0, 625), (40000, 1250, 900, 1777, 0, 0), (10000, 1000, 683, 1366, 0, 658),
+    (30000, 1000, 820, 1639, 2, 591), (30000, 1000, 820, 1639, 2, 1771), (30000, 1000, 820, 1639, 2, 1772),
+    (30000, 1000, 820, 1639, 2, 2952), (30000, 1000, 832, 1660, 1, 1200), (40000, 1250, 1216, 2431, 2, 3200),
+    (30000, 1000, 820, 1639, 2, 300)])
+def test_chirp_route_matches_numpy(lib, n, LP, p0, nonzero, nwin, jn):
+    """Rows that need few modes: the chirp transform (a forward transform of length 2 LP, one more per window) gives
+    every mode j <= jn of a row that is zero from packed sample p0 on - numpy's rfft to rounding (relative to the
+    largest mode) - in the central window (jn <= Jw) and in the one-sided window pairs beyond it."""
     rng = np.random.default_rng(n + LP + p0 + jn)
     y = np.zeros(n)
     y[:nonzero] = rng.standard_normal(nonzero) * np.exp(-np.linspace(0, 3, nonzero))
     M = n // 2
     out = np.zeros(M + 1)
-    assert jn <= lib.ldsfft_chirp_window(n, LP, p0)
-    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, n, LP, p0, 512, jn, out.ctypes.data) == 0
+    assert jn <= lib.ldsfft_chirp_window(n, LP, p0, nwin)
+    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, n, LP, p0, nwin, 512, jn, out.ctypes.data) == 0
     ref = np.fft.rfft(y)
     scale = np.max(np.abs(ref))
     need = np.arange(1, jn + 1)
@@ -127,7 +131,7 @@ def test_chirp_route_refuses_modes_outside_its_window(lib):
     y = np.zeros(30000)
     y[:1600] = 1.0
     out = np.zeros(15001)
-    jw = lib.ldsfft_chirp_window(30000, 1000, 820)
-    assert jw == 590
-    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 820, 512, jw + 1, out.ctypes.data) == 5
-    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 700, 512, 10, out.ctypes.data) == 4    # support > p0
+    jw = lib.ldsfft_chirp_window(30000, 1000, 820, 0)
+    assert jw == 590 and lib.ldsfft_chirp_window(30000, 1000, 820, 2) == 590 + 2 * 1181
+    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 820, 0, 512, jw + 1, out.ctypes.data) == 5
+    assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 700, 0, 512, 10, out.ctypes.data) == 4    # support > p0

@@ -6,7 +6,7 @@ R=${1:-3}; shift || true
 for i in $(seq $R); do
   for v in base new; do
     if [ $v = base ]; then export HMG_LIB_PATH=$PWD/hmvec_amd/libhmgrid_base.so; else unset HMG_LIB_PATH; fi
-    python bench.py --no-cpu-baseline --no-limber --steps 40 "$@" > /tmp/ab_$v.json
+    python bench.py --no-cpu-baseline --no-limber --no-readme --no-long-grid --steps 40 "$@" > /tmp/ab_$v.json
     python - $v <<'PY'
 import json, sys
 d = json.loads(open(f"/tmp/ab_{sys.argv[1]}.json").read().strip().splitlines()[-1])

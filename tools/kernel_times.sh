@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for nz in ${1:-32 4}; do
-  rocprofv3 --kernel-trace --stats -d gpurun_out/kt_$nz -o k --output-format csv -- python3 bench.py --nz $nz --no-cpu-baseline --no-limber --no-readme --steps 30 > gpurun_out/kt_$nz.log 2>&1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/kt_$nz -o k --output-format csv -- python3 bench.py --nz $nz --no-cpu-baseline --no-limber --no-readme --no-long-grid --steps 30 > gpurun_out/kt_$nz.log 2>&1
   echo "== nz=$nz"
   python3 - gpurun_out/kt_$nz/k_kernel_stats.csv <<'PY'
 import csv, sys

@@ -5,7 +5,7 @@ VARS="$1"; PAT="${2:-}"; shift; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for v in $VARS; do
   export HMG_LIB_PATH=$PWD/hmvec_amd/libhmgrid_$v.so
-  rocprofv3 --kernel-trace --stats -d gpurun_out/ktv_$v -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber --no-readme --steps 30 "$@" > gpurun_out/ktv_$v.log 2>&1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/ktv_$v -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber --no-readme --no-long-grid --steps 30 "$@" > gpurun_out/ktv_$v.log 2>&1
   python3 - gpurun_out/ktv_$v/k_kernel_stats.csv "$v" "$PAT" <<'PY'
 import csv, sys
 tot = 0.0

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for i in $(seq $R); do
 for v in $VARS; do
   if [ $v = main ]; then unset HMG_LIB_PATH; else export HMG_LIB_PATH=$PWD/hmvec_amd/libhmgrid_$v.so; fi
-  timeout -k 10 200 python3 bench.py --nxs 30000 --xmax 50 --no-cpu-baseline --no-limber --no-readme --steps 24 --warmup 3 > /tmp/lv_$v.json 2>/tmp/lv_$v.err || { echo "$v FAILED"; tail -5 /tmp/lv_$v.err; continue; }
+  timeout -k 10 200 python3 bench.py --nxs 30000 --xmax 50 --no-cpu-baseline --no-limber --no-readme --no-long-grid --steps 24 --warmup 3 > /tmp/lv_$v.json 2>/tmp/lv_$v.err || { echo "$v FAILED"; tail -5 /tmp/lv_$v.err; continue; }
   python3 - $v <<'PY'
 import json, sys
 d = json.loads(open(f"/tmp/lv_{sys.argv[1]}.json").read().strip().splitlines()[-1])

@@ -7,7 +7,7 @@ OUT=gpurun_out/pmc_sq; mkdir -p $OUT
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d $OUT/g$i -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph $PMC_BENCH_FLAGS > $OUT/g$i.log 2>&1 || { tail -5 $OUT/g$i.log; exit 1; }
+  rocprofv3 --pmc $grp -d $OUT/g$i -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-readme --no-long-grid --no-graph $PMC_BENCH_FLAGS > $OUT/g$i.log 2>&1 || { tail -5 $OUT/g$i.log; exit 1; }
 done
 python3 - $OUT "${1:-}" <<'PY'
 import csv, glob, re, sys
@@ -21,7 +21,7 @@ for f in glob.glob(f"{out}/g*/p_counter_collection.csv"):
 import json
 sys.path.insert(0, ".")
 from hmvec_amd._native import kernel_source_sha16
-json.dump({"source_sha16": kernel_source_sha16(), "source": "rocprofv3 --pmc <SQ group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph "
+json.dump({"source_sha16": kernel_source_sha16(), "source": "rocprofv3 --pmc <SQ group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-readme --no-long-grid --no-graph "
                      "(tools/pmc_kernel.sh); per-launch averages",
            "kernels": {k: {c: tot[k][c] / n[k][c] for c in sorted(tot[k])} for k in sorted(tot)}},
           open(f"{out}/sq_issue_counters.json", "w"), indent=1)

@@ -12,7 +12,7 @@ ROOT="$GRAFT_REPO_ROOT"; [ -z "$ROOT" ] && ROOT="$(cd "$(dirname "$0")/.." && pw
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-readme --no-long-grid --no-graph > $OUT/pmc_$c.log 2>&1
 done
 cp $OUT/pmc_FETCH_SIZE/p_counter_collection.csv $OUT/pmc_fetch_counter_collection.csv
 cp $OUT/pmc_WRITE_SIZE/p_counter_collection.csv $OUT/pmc_write_counter_collection.csv
@@ -39,7 +39,7 @@ sys.path.insert(0, ".")
 from hmvec_amd._native import kernel_source_sha16
 res = {"source_sha16": kernel_source_sha16(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
-                 "--no-cpu-baseline --no-limber --no-graph; Config 3, 1 GPU (tools/profile_round.sh)",
+                 "--no-cpu-baseline --no-limber --no-readme --no-long-grid --no-graph; Config 3, 1 GPU (tools/profile_round.sh)",
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
                      "MI355X_MICROARCH.md, HBM section)",
        "kernels": {k: {"FETCH_SIZE_KB_per_launch": f.get(k, 0.0), "WRITE_SIZE_KB_per_launch": w.get(k, 0.0),
@@ -59,6 +59,6 @@ cp $OUT/pmc_traffic.json $OUT/sq_issue_counters.json profiles/$ROUND/
 echo "counters done"
 python3 bench.py > $OUT/config3_bench.json
 echo "bench done"
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-limber --no-readme --no-long-grid > $OUT/kt.log 2>&1
 cp $OUT/kt/k_kernel_stats.csv $OUT/config3_kernel_stats.csv
 echo "kernel trace done"

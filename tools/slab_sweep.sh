@@ -3,7 +3,7 @@
 # 1/2/4/8-GPU job computes).  Usage: tools/slab_sweep.sh [extra bench.py flags]; env passes through.
 set -e
 for nz in ${SLABS:-32 16 8 4}; do
-  python bench.py --nz $nz --no-cpu-baseline --no-limber --no-readme --steps 50 "$@" > /tmp/slab_$nz.json
+  python bench.py --nz $nz --no-cpu-baseline --no-limber --no-readme --no-long-grid --steps 50 "$@" > /tmp/slab_$nz.json
   python - $nz <<'PY'
 import json, sys
 d = json.loads(open(f"/tmp/slab_{sys.argv[1]}.json").read().strip().splitlines()[-1])
