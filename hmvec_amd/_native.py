@@ -199,7 +199,7 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
-    for name in ("hmgrid.hip", "sici.hpp", "ldsfft.hpp", "fastmath.hpp", "Makefile"):
+    for name in ("hmgrid.hip", "longgrid.hip", "longgrid.hpp", "rowdev.hpp", "sici.hpp", "ldsfft.hpp", "fastmath.hpp", "Makefile"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -23,6 +23,8 @@
 #include "../../include/hmgrid.h"
 #include "fastmath.hpp"
 #include "ldsfft.hpp"
+#include "rowdev.hpp"
+#include "longgrid.hpp"
 #include "sici.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -207,29 +209,7 @@ static int ensure_scratch(hmg_ctx* c, int slot, size_t bytes) {
 // ------------------------------------------------------------------------------------------
 namespace hmg {
 
-constexpr int WAVE = 64;
-
-// Sum over the 64 lanes of a wavefront, returned in EVERY lane.  Cross-lane moves are DPP modifiers
-// (register-to-register, a few cycles) instead of __shfl (ds_bpermute: an LDS-pipeline round trip per
-// step, twelve dependent ones per double).  Fixed combination tree: pairs, quads, half rows, rows of 16
-// (quad_perm / row_half_mirror / row_mirror leave every lane of a row with the row's sum), then
-// row 0 -> 1 and 2 -> 3 (row_bcast:15), rows 0+1 -> 2,3 (row_bcast:31); lane 63 holds the total.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_move<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-    v += dpp_move<0x141, 0xf>(v);     // row_half_mirror
-    v += dpp_move<0x140, 0xf>(v);     // row_mirror
-    v += dpp_move<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3 (other rows receive 0)
-    v += dpp_move<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
-                            __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
+// (WAVE, dpp_move, wave_sum: rowdev.hpp - shared with the long-grid kernels of longgrid.hip)
 
 // Sum over a 1-D block (blockDim.x multiple of 64, <= 1024).  Result valid in thread 0.
 __device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubles */) {
@@ -1106,21 +1086,7 @@ __global__ __launch_bounds__(256) void interp_kernel(int nm, int nk, int nh, int
 // Used when nxs is even, nxs/2 factors into 5/4/3/2 and fits LDS; otherwise hmg_profile_fft
 // falls back to the chunked rocFFT path.
 // (UnpackTw - the per-mode constants of the unpack step, one 32-byte load - lives in ldsfft.hpp)
-struct FusedArgs {
-    FftPlanDev plan;
-    int nxs, nm, nk, do_norm;
-    const double* xs;
-    const cplx* twM;     // exp(-2 pi i t / M), t < M
-    const UnpackTw* twN; // (cos, sin)(2 pi j / nxs), 1/j, 1/(M-j) for j <= M/2
-    const double* kts;
-    const double *amp, *xc, *alpha, *expo;
-    double amp_c, xc_c, alpha_c, expo_c, gamma, step;
-    const double *cmax, *rss, *zs, *ks, *post;
-    double* out;
-    int* nconst;               // optional constant-prefix hint per row
-    double* cconst;
-    const double* logx;        // ln xs[n], shared by every row (nullptr: evaluated per sample)
-};
+// (FusedArgs - the description of a launch of radial-profile rows - lives in rowdev.hpp)
 
 // ln x_n of the radial grid: the same for all (z,m) rows, so with many rows one small launch replaces a
 // quarter of the integrand's transcendentals (same log_fast as the in-kernel path: identical bits).
@@ -1129,15 +1095,7 @@ __global__ void logx_kernel(int n, const double* __restrict__ xs, double* __rest
     if (i < n) out[i] = log_fast(xs[i]);
 }
 
-// amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two
-// powers of t) with the short fp64 log/exp/log1p of fastmath.hpp (< 2 ulp each, host-tested):
-// ~100 VALU ops per sample instead of ~190 with the device library's and ~700 with three pow().
-__device__ __forceinline__ double gnfw_rho_fast(double lt /* ln(x/xc) */, double A, double AL, double EX,
-                                                double gamma) {
-    // (|exponents| stay far below 1e9: no clamp; the logarithm's absolute error is what the outer exp sees)
-    const double ta = exp_fast<false>(fmin(AL * lt, 700.0));
-    return A * exp_fast<false>(gamma * lt - EX * log1p_abs(ta));
-}
+// (gnfw_rho_fast: rowdev.hpp)
 
 template <int NT, int R, int MAXB, bool SMALL = false, int NIN = R, int SRC_SHIFT = 0>
 __device__ __forceinline__ void fused_pass(cplx* buf, const cplx* __restrict__ twM, int M, int Ns, int twstep,
@@ -1468,343 +1426,9 @@ __global__ __launch_bounds__(NT, (fused_occ<MAXB, SPECM>())) void profile_fused_
     profile_fused_row<NT, MAXB, MAXP, SPECM>(A, blockIdx.x, smem);
 }
 
-// ---------------------------------------------------------------- K45p: long radial grids with short support
-// nxs = 30000 / 40000 - what the reference's own callers pass (examples/lensing_baryons.py:27 and bin/tests.py:308:
-// add_battaglia_profile(xmax=50, nxs=30000); hmvec/params.py:59-60: numeric NFW, nxs = 40000, xmax = 200) - do not
-// fit LDS as one packed row (M = nxs/2 complex = 240-320 KB), but the profile is cut at cmax << xmax: only the first
-// P0 = ceil(#{x_n <= cmax} / 2) packed samples are non-zero (820 of 15000 for the gas profile at xmax = 50).  With
-// LP >= P0, M = R LP, the transform is R transforms of length LP of the row times W_M^{rp} (ldsfft.hpp, "pruned
-// decomposition"): one workgroup per (z,m) row keeps the P0 samples in LDS, transforms the residues r and R - r
-// side by side with the compile-time plan of length LP, unpacks the pair on the spot into u_j (a per-row scratch
-// line in HBM/L2: up to M modes do not fit LDS either) and interpolates as the fused kernel does.  Nothing of
-// length nxs is ever written: the rocFFT route this replaces moves 2*8*nxs + 2*16*(nxs/2+1) bytes per row.
-struct PrunedArgs {
-    FusedArgs F;          // the row description (F.plan is not used)
-    int M, R;             // packed length nxs/2 = R * LP
-    const cplx* twB;      // exp(-2 pi i t / M), t < M
-    const cplx* twL;      // exp(-2 pi i t / LP), t < LP
-    double* u;            // [rows of this launch][M]: u_j at [j-1]
-    int* fault;           // set when a row's support turns out longer than LP (stale support bound)
-    int row0;             // first row of this launch
-    // chirp route for rows that need few modes (ldsfft.hpp; nullptr: every row takes the decomposition)
-    const cplx* chP;      // ch(p), p < LP
-    const cplx* chJ;      // ch(j), j <= Jw
-    const cplx* Bw;       // transform of the chirp window / Lc, Lc = 2 LP
-    const cplx* twC;      // exp(-2 pi i t / Lc)
-    int Jw, p0;           // modes |j| <= Jw are in the window; it was built for supports of <= p0 packed samples
-};
-
-// The passes 1 .. npass-1 of the sub-transforms (pass 0 runs from registers, profile_pruned_row).
-// (Measured and dropped, MI355X: a thread works on the same butterflies in every group of residues, so its twiddle
-// per pass can be fetched once per row and held in registers - 16 more VGPRs at LP = 1000 spill inside the group loop
-// under the 64- and the 80-register caps alike: 1.16 -> 2.38 / 2.04 ms.)
-#ifndef HMG_PRUNED_TWLDS
-#define HMG_PRUNED_TWLDS 0
-#endif
-template <int NT, int LP, int PS, int NBUF = 2>
-__device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* twL, int nbuf, int keep) {
-    if constexpr (PS < SubPass<LP, 0>::P.npass) {
-        using S = SubPass<LP, PS>;
-        constexpr int MAXB = (NBUF * S::nb + NT - 1) / NT;
-        cplx v[MAXB][S::R];
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            const int jj = threadIdx.x + b * NT;
-            if (sub_pass_active<LP, PS>(jj, nbuf, keep)) sub_pass_load<LP, PS>(buf, twL, jj, v[b]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            const int jj = threadIdx.x + b * NT;
-            if (sub_pass_active<LP, PS>(jj, nbuf, keep)) sub_pass_store<LP, PS>(buf, jj, v[b]);
-        }
-        __syncthreads();
-        pruned_passes<NT, LP, PS + 1, NBUF>(buf, twL, nbuf, keep);
-    }
-}
-// lengths whose chirp route is compiled in: the thread that owns the samples j, j + LP/2 of the decomposition's
-// radix-2 first pass owns exactly the two non-zero inputs of butterfly j of the radix-4 first pass at Lc = 2 LP
-template <int LP> constexpr bool chirp_ok() {
-    if constexpr (LP == 1000 || LP == 1250) return SubPass<LP, 0>::R == 2 && SubPass<2 * LP, 0>::R == 4;
-    else return false;
-}
-
-template <int NT, int LP>
-__device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row, double* smem) {
-    const FusedArgs& A = G.F;
-    // dynamic LDS: [0, 2 LP) cplx = the two transform buffers, then 32 doubles of scalars laid out as in
-    // profile_fused_row.  The packed samples of the row stay in REGISTERS: thread j < LP/R0 owns the R0 inputs
-    // j + t LP/R0 of butterfly j of the first pass (radix R0, sub-transform size 1: no pass twiddles), so the
-    // multiplication by W_M^{rp} and the first pass of every residue's transform need no LDS read at all.
-    cplx* buf = reinterpret_cast<cplx*>(smem);
-    double* red = smem + 4 * (size_t)LP;
-    int* s_cnt = reinterpret_cast<int*>(red + 17);
-    int* s_jn = reinterpret_cast<int*>(red + 18);
-#if HMG_PRUNED_TWLDS
-    // the twiddle table of the sub-transforms in LDS behind the scalars: the passes of the group loop then make no
-    // global access at all (one ds_read_b128 per butterfly instead of an L2 round trip per pass)
-    cplx* twl = reinterpret_cast<cplx*>(red + 32);
-    for (int t = threadIdx.x; t < LP; t += NT) twl[t] = G.twL[t];
-#else
-    const cplx* __restrict__ twl = G.twL;
-#endif
-    using S0 = SubPass<LP, 0>;
-    constexpr int R0 = S0::R, nb0 = S0::nb, MAXB0 = (nb0 + NT - 1) / NT;
-    static_assert(S0::Ns == 1, "first pass");
-    const int M = G.M, R = G.R, nxs = 2 * M;
-    const double Aamp = A.amp ? A.amp[row] : A.amp_c;
-    const double XC = A.xc ? A.xc[row] : A.xc_c;
-    const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
-    const double EX = A.expo ? A.expo[row] : A.expo_c;
-    const double cm = A.cmax[row];
-    const double ln_xc = (A.xc == nullptr && A.xc_c == 1.0) ? 0.0 : log_fast(XC);
-    const int z = row / A.nm;
-    double* __restrict__ dst = A.out + (size_t)row * A.nk;
-    // The plan was sized from a bound on the support (profile_support); a row that exceeds it cannot be transformed
-    // here: it is filled with NaN and the context's fault word is raised, which the next synchronising call reports.
-    if (!(A.xs[2 * LP] > cm)) {                    // (2 LP < nxs: R >= 2; xs increasing)
-        for (int i = threadIdx.x; i < A.nk; i += NT) dst[i] = __builtin_nan("");
-        if (threadIdx.x == 0) {
-            atomicOr(G.fault, 1);
-            if (A.nconst) { A.nconst[row] = 0; A.cconst[row] = __builtin_nan(""); }
-        }
-        return;
-    }
-    // row scalars and the end of the left-fill prefix: the last wavefront, as in profile_fused_row
-    if (threadIdx.x >= NT - 64) {
-        const int lane = threadIdx.x & 63;
-        const double isc0 = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));
-        const double klo0 = A.kts[1] * isc0;
-        const double idk0 = 1.0 / klo0;
-        int jn0 = M, nleft = 0;
-        if (A.nconst) {
-            const double tmax = A.ks[A.nk - 1] * idk0;
-            if (tmax < (double)(M - 4)) jn0 = (int)tmax + 3;
-            int base = 0, end = A.nk;
-            for (;;) {
-                const int stp = (end - base + 63) >> 6;
-                const int first = base + lane * stp;
-                bool below = false;
-                if (first < end) {
-                    const int last = first + stp - 1;
-                    below = A.ks[last < end ? last : end - 1] < klo0;
-                }
-                base += __popcll(__ballot(below)) * stp;
-                if (base >= end) { base = end; break; }
-                if (stp == 1) break;
-                end = base + stp < end ? base + stp : end;
-            }
-            nleft = base;
-        }
-        if (lane == 0) {
-            *s_cnt = nleft;
-            *s_jn = jn0;
-            red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
-            red[23] = 1.0 / A.kts[1];
-        }
-    }
-    // ---- phase A: the LP packed samples that can be non-zero (into registers), and the mass norm
-    cplx zp[MAXB0][R0];
-    double acc = 0.0;
-#pragma unroll
-    for (int b = 0; b < MAXB0; ++b) {
-#pragma unroll
-        for (int t = 0; t < R0; ++t) {
-            const int jb = threadIdx.x + b * NT;
-            zp[b][t] = cplx{0.0, 0.0};
-            if (jb < nb0) {
-                const int j = 2 * (jb + t * nb0);
-                const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
-                double r0 = 0.0, r1 = 0.0;
-                if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
-                if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
-                zp[b][t] = cplx{xv.x * r0, xv.y * r1};
-                if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
-                    const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
-                    acc += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
-                }
-            }
-        }
-    }
-    {
-        const double ws = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
-        __syncthreads();
-    }
-    if (threadIdx.x < 64) {
-        double tot = red[0];
-#pragma unroll
-        for (int w = 1; w < NT / 64; ++w) tot += red[w];
-        const double mnorm = A.do_norm ? tot : 1.0;
-        if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
-    }
-    const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
-    // ---- phase B + C: per group of residues {g, R - g}: first pass from registers, the other passes in LDS,
-    // unpack into the scratch line
-    double* __restrict__ u = G.u + (size_t)(row - G.row0) * M;
-    constexpr int nb_last = SubPass<LP, S0::P.npass - 1>::nb;
-    const int keep = pruned_keep(R, M, nb_last, jn);
-    bool chirped = false;
-    if constexpr (chirp_ok<LP>()) {
-        // ---- rows that need few modes: the chirp route - two transforms of length 2 LP instead of R of length LP
-        // (the window was built for supports up to p0 packed samples: a row beyond it takes the decomposition)
-        if (G.Bw != nullptr && jn <= G.Jw && A.xs[2 * G.p0 < nxs ? 2 * G.p0 : nxs - 1] > cm) {
-            chirped = true;
-            constexpr int LC = 2 * LP;
-            using C0 = SubPass<LC, 0>;
-            static_assert(C0::nb == nb0 && MAXB0 == (C0::nb + NT - 1) / NT, "sample ownership");
-            constexpr int nb_last_c = SubPass<LC, C0::P.npass - 1>::nb;
-#pragma unroll
-            for (int b = 0; b < MAXB0; ++b) {
-                const int jb = threadIdx.x + b * NT;
-                if (jb < nb0) {
-                    cplx v[4];
-                    chirp_first_pass(zp[b][0], zp[b][1], G.chP[jb], G.chP[jb + nb0], v);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) buf[4 * jb + t] = v[t];
-                }
-            }
-            __syncthreads();
-            pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, -1);
-            {   // product with the window's transform, fused into the first pass of the second transform
-                cplx v[MAXB0][4];
-#pragma unroll
-                for (int b = 0; b < MAXB0; ++b) {
-                    const int jb = threadIdx.x + b * NT;
-                    if (jb < nb0) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[b][t] = cmul(buf[jb + t * nb0], G.Bw[jb + t * nb0]);
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int b = 0; b < MAXB0; ++b) {
-                    const int jb = threadIdx.x + b * NT;
-                    if (jb < nb0) {
-                        dft_small<4>(v[b]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) buf[4 * jb + t] = v[b][t];
-                    }
-                }
-                __syncthreads();
-            }
-            pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, (2 * jn + 2 < nb_last_c) ? jn : -1);
-            const double sc = red[24];
-            for (int j = 1 + (int)threadIdx.x; j <= jn; j += NT) {
-                const UnpackTw w = A.twN[j];
-                u[j - 1] = chirp_unpack(buf, LC, j, G.chJ[j], w) * sc * w.rj;
-            }
-        }
-    }
-    for (int g = 0; g <= R / 2 && !chirped; ++g) {
-        if (!pruned_group_needed(R, M, g, jn)) break;          // (groups are needed in ascending order of g)
-        const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
-#pragma unroll
-        for (int b = 0; b < MAXB0; ++b) {
-            const int jb = threadIdx.x + b * NT;
-            if (jb < nb0) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (h < nbuf) {
-                        const int sres = h ? s1 : g;
-                        cplx v[R0];
-#pragma unroll
-                        for (int t = 0; t < R0; ++t) v[t] = cmul(zp[b][t], G.twB[sres * (jb + t * nb0)]);
-                        dft_small<R0>(v);
-#pragma unroll
-                        for (int t = 0; t < R0; ++t) buf[h * LP + jb * R0 + t] = v[t];      // Ns = 1: q = j, k = 0
-                    }
-                }
-            }
-        }
-        __syncthreads();                                       // (also publishes red[24] before the first unpack)
-        pruned_passes<NT, LP, 1>(buf, twl, nbuf, keep);
-        const double sc = red[24];
-        pruned_unpack(buf, LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
-        if (nbuf == 2) pruned_unpack(buf, LP, R, M, s1, 1, 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
-        __syncthreads();                                       // the next group overwrites the buffers
-    }
-    if (threadIdx.x == 0) u[M - 1] = 0.0;                      // Nyquist mode: Im F_M == 0
-    __threadfence_block();
-    __syncthreads();                                           // u (global) is read by other threads below
-    // ---- phase D: as profile_fused_row, the modes read from the scratch line
-    const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
-    const double pf = A.post ? A.post[row] : 1.0;
-    const double u1 = u[0];
-    const int nleft = A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0;
-    if (nleft > 0) {
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        const double c = u1 * pf;
-        const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-        const int npair = (nleft - head) >> 1;
-        v2d* __restrict__ d2 = reinterpret_cast<v2d*>(dst + head);
-        const v2d cc = {c, c};
-        for (int q = threadIdx.x; q < npair; q += NT) __builtin_nontemporal_store(cc, &d2[q]);
-        if (threadIdx.x == 0) {
-            if (head) __builtin_nontemporal_store(c, &dst[0]);
-            if ((nleft - head) & 1) __builtin_nontemporal_store(c, &dst[nleft - 1]);
-        }
-    }
-    auto interp = [&](double k) {
-        int j = (int)(k * inv_dk);
-        j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
-        const double fr = fma(k, inv_dk, -(double)j);
-        const double y0 = u[j - 1], y1 = u[j];
-        return fma(y1 - y0, fr, y0);
-    };
-    if (A.nconst) {
-        for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
-            if (i < nleft) continue;
-            const double k = A.ks[i];
-            const double val = k > k_hi ? 0.0 : interp(k);
-            __builtin_nontemporal_store(val * pf, &dst[i]);
-        }
-    } else {
-        for (int i = threadIdx.x; i < A.nk; i += NT) {
-            const double k = A.ks[i];
-            const double val = k < k_lo ? u1 : (k > k_hi ? 0.0 : interp(k));
-            __builtin_nontemporal_store(val * pf, &dst[i]);
-        }
-    }
-    if (A.nconst && threadIdx.x == 0) {
-        A.nconst[row] = nleft;
-        A.cconst[row] = u1 * pf;
-    }
-}
-#ifndef HMG_PRUNED_OCC
-#define HMG_PRUNED_OCC 0
-#endif
-// waves per SIMD the LDS footprint (two buffers of LP complex numbers [+ the twiddle table]) allows a 512-thread
-// workgroup: 2 per workgroup
-template <int LP> constexpr int pruned_occ() {
-    constexpr int wgs = (160 * 1024) / ((2 + HMG_PRUNED_TWLDS) * LP * 16 + 256);
-    return HMG_PRUNED_OCC ? HMG_PRUNED_OCC : (wgs >= 4 ? 8 : 2 * wgs);
-}
-template <int NT, int LP>
-__global__ __launch_bounds__(NT, pruned_occ<LP>()) void profile_pruned_kernel(PrunedArgs G) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    profile_pruned_row<NT, LP>(G, G.row0 + blockIdx.x, smem);
-}
-
-// Upper bound of the support of a launch's rows: max over rows of the number of PACKED samples that can be non-zero,
-// ceil(#{n : x_n <= cmax[row]} / 2) (xs increasing; the mask of hmvec/fft.py:81 is strict, |x| > cmax).
-__global__ void profile_support_kernel(int rows, int nxs, const double* __restrict__ xs, const double* __restrict__ cmax,
-                                       int* __restrict__ out) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    int p0 = 0;
-    if (row < rows) {
-        const double cm = cmax[row];
-        int lo = 0, hi = nxs;                       // first n with xs[n] > cm
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (xs[mid] > cm) hi = mid; else lo = mid + 1;
-        }
-        p0 = (lo + 1) >> 1;
-        if (!(cm == cm)) p0 = nxs;                  // NaN cmax: nothing is masked (|x| > NaN is false)
-    }
-    for (int off = 32; off; off >>= 1) p0 = max(p0, __shfl_xor(p0, off));
-    if ((threadIdx.x & 63) == 0 && p0 > 0) atomicMax(out, p0);
-}
+// (K45p, the long radial grids with short support - profile_pruned_kernel and the chirp route: longgrid.hip, a
+// translation unit of its own.  In this one the mere presence of its instantiations changed the address arithmetic
+// hipcc emits for profile_group_kernel<2,3,2500> - 605 instead of 593 VALU instructions per wavefront.)
 
 // ---------------------------------------------------------------- K7: HOD (H1-H3)
 // 10^y and x^p through exp2/log2 (one transcendental each instead of the ~6x longer generic
@@ -3785,10 +3409,7 @@ static int get_plan(hmg_ctx* c, int nxs, int batch, FftPlan** out) {
     return 0;
 }
 
-#ifndef HMG_FUSED_NT
-#define HMG_FUSED_NT 512
-#endif
-constexpr int FUSED_NT = HMG_FUSED_NT;   // threads per row workgroup of the fused profile kernel
+// (FUSED_NT, the threads per row workgroup of the fused profile kernels: rowdev.hpp)
 
 // Workgroup-FFT tables for a given nxs; returns nullptr (no error) when the fused kernel
 // cannot take this length.
@@ -3919,28 +3540,12 @@ static int profile_support(hmg_ctx* c, int rows, int nxs, const double* xs, cons
     if (ensure_scratch(c, 2, 64)) return 1;
     int* d_p0 = (int*)c->scratch[2];
     HIP_TRY(hipMemsetAsync(d_p0, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(profile_support_kernel, grid1d((size_t)rows, 256), dim3(256), 0, c->stream, rows, nxs, xs, cmax, d_p0);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY((hipError_t)launch_profile_support(c->stream, rows, nxs, xs, cmax, d_p0));
     int h = 0;
     HIP_TRY(hipMemcpyAsync(&h, d_p0, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->support[key] = h;
     *p0max = h;
-    return 0;
-}
-
-template <int LP>
-static int launch_pruned(hmg_ctx* c, PrunedArgs G, int rows, size_t rows_per_launch) {
-    const size_t lds = (size_t)(2 + HMG_PRUNED_TWLDS) * LP * 16 + 32 * sizeof(double);
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)profile_pruned_kernel<FUSED_NT, LP>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int r0 = 0; r0 < rows; r0 += (int)rows_per_launch) {
-        const int nr = rows - r0 < (int)rows_per_launch ? rows - r0 : (int)rows_per_launch;
-        G.row0 = r0;
-        hipLaunchKernelGGL((profile_pruned_kernel<FUSED_NT, LP>), dim3(nr), dim3(FUSED_NT), lds, c->stream, G);
-        HIP_TRY(hipGetLastError());
-    }
     return 0;
 }
 
@@ -3991,15 +3596,8 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
     }
     int rc = 1, stop = -1;
     if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
-    switch (LP) {
-        case 1000: rc = launch_pruned<1000>(c, G, rows, rpl); break;
-        case 1024: rc = launch_pruned<1024>(c, G, rows, rpl); break;
-        case 1250: rc = launch_pruned<1250>(c, G, rows, rpl); break;
-        case 1500: rc = launch_pruned<1500>(c, G, rows, rpl); break;
-        case 2000: rc = launch_pruned<2000>(c, G, rows, rpl); break;
-        case 2048: rc = launch_pruned<2048>(c, G, rows, rpl); break;
-        case 2500: rc = launch_pruned<2500>(c, G, rows, rpl); break;
-    }
+    HIP_TRY((hipError_t)launch_pruned(c->stream, LP, G, rows, rpl));
+    rc = 0;
     if (rc) return 1;
     c->fault_armed = true;
     *taken = 1;

@@ -1,0 +1,31 @@
+// Interface between hmgrid.hip (contexts, plans, the C ABI) and longgrid.hip (the long-grid row kernels, compiled as
+// a translation unit of their own).  Host functions return a hipError_t as int.
+#pragma once
+#include "rowdev.hpp"
+
+namespace hmg {
+
+struct PrunedArgs {
+    FusedArgs F;          // the row description (F.plan is not used)
+    int M, R;             // packed length nxs/2 = R * LP
+    const cplx* twB;      // exp(-2 pi i t / M), t < M
+    const cplx* twL;      // exp(-2 pi i t / LP), t < LP
+    double* u;            // [rows of this launch][M]: u_j at [j-1]
+    int* fault;           // set when a row's support turns out longer than LP (stale support bound)
+    int row0;             // first row of this launch
+    // chirp route for rows that need few modes (ldsfft.hpp; nullptr: every row takes the decomposition)
+    const cplx* chP;      // ch(p), p < LP
+    const cplx* chJ;      // ch(j), j <= Jw
+    const cplx* Bw;       // transform of the chirp window / Lc, Lc = 2 LP
+    const cplx* twC;      // exp(-2 pi i t / Lc)
+    int Jw, p0;           // modes |j| <= Jw are in the window; it was built for supports of <= p0 packed samples
+};
+
+// sub-transform lengths LP that are compiled in
+bool pruned_lp_compiled(int LP);
+// rows [0, rows) of G in launches of at most rows_per_launch rows (the scratch line block G.u holds that many)
+int launch_pruned(hipStream_t stream, int LP, PrunedArgs G, int rows, size_t rows_per_launch);
+// *d_out = max over rows of the packed samples that can be non-zero (d_out must be zero before)
+int launch_profile_support(hipStream_t stream, int rows, int nxs, const double* xs, const double* cmax, int* d_out);
+
+}  // namespace hmg

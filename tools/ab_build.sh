@@ -5,8 +5,8 @@ set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 T=$(mktemp -d)
 mkdir -p $T/hmvec_amd/csrc $T/include
-for f in hmgrid.hip sici.hpp ldsfft.hpp fastmath.hpp Makefile; do git -C $ROOT show HEAD:hmvec_amd/csrc/$f > $T/hmvec_amd/csrc/$f; done
+for f in hmgrid.hip longgrid.hip longgrid.hpp rowdev.hpp sici.hpp ldsfft.hpp fastmath.hpp Makefile; do git -C $ROOT show HEAD:hmvec_amd/csrc/$f > $T/hmvec_amd/csrc/$f; done
 git -C $ROOT show HEAD:include/hmgrid.h > $T/include/hmgrid.h
-make -C $T/hmvec_amd/csrc OUT=$ROOT/hmvec_amd/libhmgrid_base.so 2>&1 | grep -E "error|warning" || true
+make -j2 -C $T/hmvec_amd/csrc OUT=$ROOT/hmvec_amd/libhmgrid_base.so 2>&1 | grep -E "error|warning" || true
 rm -rf $T
 ls -la $ROOT/hmvec_amd/libhmgrid_base.so

@@ -26,9 +26,9 @@ KERNELS = [   # (label, regex on the mangled name)
 
 def main():
     if "--no-build" not in sys.argv:
-        subprocess.run(["make", "-C", CSRC, "asm"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    res = open(os.path.join(CSRC, "hmgrid.resources.txt")).read()
-    asm = open(os.path.join(CSRC, "hmgrid.s")).read()
+        subprocess.run(["make", "-j2", "-B", "-C", CSRC, "asm"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res = open(os.path.join(CSRC, "hmgrid.resources.txt")).read() + open(os.path.join(CSRC, "longgrid.resources.txt")).read()
+    asm = open(os.path.join(CSRC, "hmgrid.s")).read() + open(os.path.join(CSRC, "longgrid.s")).read()
     from hmvec_amd._native import kernel_source_sha16
     print(f"# kernel sources {kernel_source_sha16()}  (hipcc -O3 --offload-arch=gfx950 -mllvm -disable-machine-licm; make asm)")
     print("# columns: SGPRs VGPRs | reserved scratch B/lane | occupancy waves/SIMD | SGPR spills, VGPR spills (compiler summary) |")
