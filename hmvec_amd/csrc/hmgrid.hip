@@ -2322,6 +2322,12 @@ __device__ __forceinline__ T kernarg_load(const T HMG_KERNARG* p) {      // a by
     for (unsigned i = 0; i < sizeof(T) / 8; ++i) u.w[i] = q[i];
     return u.v;
 }
+// ROLES OF A GROUPED LAUNCH (chain_row, rows_block, massfn_block, nfw_rows, profile_fused_row, the front's roles) ARE
+// __forceinline__ INTO THEIR __global__ KERNEL AND TAKE KERNEL PARAMETERS BY VALUE.  Round 3 tried a role as a
+// `noinline` function with its arguments behind a pointer: hipcc 7.2 lost the thread index on one path of it and part
+// of a workgroup skipped a barrier (a launch that never finished); read through __builtin_amdgcn_kernarg_segment_ptr()
+// INSIDE a called function the argument block sits at address 0 (a memory fault).  DESIGN.md section 3, "What stalled
+// and what aborted in round 3".
 template <int NT>
 __device__ __forceinline__ void chain_row(const ChainArgs& C, int z, double* lds) {
     if (C.has_hod) {
