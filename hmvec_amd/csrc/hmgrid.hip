@@ -1144,8 +1144,8 @@ template <int SPECM> constexpr int fused_first_radix() {
 // run-time plan needs ~91 registers for its pass loop and dispatch chain; measured on the Config-3 grid at
 // nxs = 3000 / 2000 (tools/shape_sweep.py): 8 waves/SIMD (64 VGPRs, 28-34 spilled, 116 B/lane) 0.294 / 0.277 ms,
 // 6 (80 VGPRs, 12 spilled, 52 B/lane) 0.263 / 0.243 ms, 5 (91 VGPRs, nothing spilled) 0.320 / 0.285 ms: 6 it is.
-// The lengths people use have compile-time plans (nxs = 1000, 2000, 4000, 5000, 10000: 0.131, 0.154, 0.193 ms
-// against 0.245, 0.285, 0.342 with the run-time plan), so this path serves the odd ones.
+// The lengths people use have compile-time plans (nxs = 1000, 2000, 4000, 5000: 0.129, 0.155, 0.193 ms for the
+// first three against 0.190, 0.238, 0.280 with this run-time plan), so this path serves the odd ones.
 #ifndef HMG_RT_OCC
 #define HMG_RT_OCC 6
 #endif
@@ -3437,6 +3437,9 @@ static int get_fused_plan(hmg_ctx* c, int nxs, FusedPlan** out) {
         }
         P.maxb = maxb;
         P.maxp = (M / 2 + FUSED_NT - 1) / FUSED_NT;
+        // (M = 5000, nxs = 10000, has five butterflies per thread in its radix-2 pass and is left to the long-grid
+        // route: measured on the Config-3 grid, one 80-KB row in LDS with a compile-time plan 0.498 ms, long-grid route
+        // 0.408 ms, rocFFT 3.26 ms - tools/probes/nxs10000_routes.py)
         ok = maxb <= 4 && P.maxp <= 8;
     }
     if (!ok) {
@@ -3674,15 +3677,14 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
                                   pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
                                   !getenv("HMG_FUSED_GENERIC");      // (testing: force the run-time plan)
             const bool grouped = C && nchain > 0 && FUSED_NT == 512;
-            // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 4000, 10000
+            // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 4000
             const int ctM = (FUSED_NT == 512 && !getenv("HMG_FUSED_GENERIC") &&
-                             (pl.M == 500 || pl.M == 1000 || pl.M == 2000 || pl.M == 5000)) ? pl.M : 0;
+                             (pl.M == 500 || pl.M == 1000 || pl.M == 2000)) ? pl.M : 0;
             if (grouped) {
                 if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds);
                 else if (ctM == 500) rc = launch_fused_group<1, 1, 500>(c, A, rows, *C, nchain, chain_lds);
                 else if (ctM == 1000) rc = launch_fused_group<1, 1, 1000>(c, A, rows, *C, nchain, chain_lds);
                 else if (ctM == 2000) rc = launch_fused_group<2, 2, 2000>(c, A, rows, *C, nchain, chain_lds);
-                else if (ctM == 5000) rc = launch_fused_group<4, 5, 5000>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 1 && mp <= 2) rc = launch_fused_group<1, 2>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 2 && mp <= 3) rc = launch_fused_group<2, 3>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 2 && mp <= 4) rc = launch_fused_group<2, 4>(c, A, rows, *C, nchain, chain_lds);
@@ -3693,7 +3695,6 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             else if (ctM == 500) rc = launch_fused<1, 1, 500>(c, A, rows);
             else if (ctM == 1000) rc = launch_fused<1, 1, 1000>(c, A, rows);
             else if (ctM == 2000) rc = launch_fused<2, 2, 2000>(c, A, rows);
-            else if (ctM == 5000) rc = launch_fused<4, 5, 5000>(c, A, rows);
             else if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
             else if (mb <= 2 && mp <= 3) rc = launch_fused<2, 3>(c, A, rows);
             else if (mb <= 2 && mp <= 4) rc = launch_fused<2, 4>(c, A, rows);

@@ -71,10 +71,14 @@ def main():
         run_case(f"nxs={nxs} xmax=20: run-time plan (HMG_FUSED_GENERIC=1)", zs, ms, ks, (nxs, 20), six,
                  env={"HMG_FUSED_GENERIC": "1"})
     run_case("nxs=3000 xmax=20: run-time plan (no compile-time plan for M=1500)", zs, ms, ks, (3000, 20), six)
-    run_case("nxs=10000 xmax=20: one row in LDS, compile-time plan M=5000 (80 KB)", zs, ms, ks, (10000, 20), six)
-    run_case("nxs=10000 xmax=20: pruned long-grid route (HMG_FUSED_MAX_M=2500)", zs, ms, ks, (10000, 20), six,
-             env={"HMG_FUSED_MAX_M": "2500"})
-    run_case("nxs=30000 xmax=50: pruned long-grid route (LP=1000, R=15)", zs, ms, ks, (30000, 50), six)
+    run_case("nxs=10000 xmax=20: long-grid route (LP=1000, R=5; one 80-KB row in LDS measured slower)", zs, ms, ks,
+             (10000, 20), six)
+    run_case("nxs=10000 xmax=20: rocFFT route (HMG_PRUNED_FFT=0)", zs, ms, ks, (10000, 20), six,
+             env={"HMG_PRUNED_FFT": "0"}, reps=5)
+    run_case("nxs=30000 xmax=50: long-grid route (LP=1000, R=15; chirp route for rows with jn <= 590)", zs, ms, ks,
+             (30000, 50), six)
+    run_case("nxs=30000 xmax=50: long-grid route without the chirp route (HMG_CHIRP=0)", zs, ms, ks, (30000, 50), six,
+             env={"HMG_CHIRP": "0"})
     run_case("nxs=30000 xmax=50: rocFFT route (HMG_PRUNED_FFT=0)", zs, ms, ks, (30000, 50), six,
              env={"HMG_PRUNED_FFT": "0"}, reps=5)
     names = ["nfw", "electron", "g", "y"]
