@@ -117,6 +117,7 @@ struct hmg_ctx {
     int use_fused_fft = 1;                         // HMG_FUSED_FFT=0 forces the rocFFT path
     int use_pruned_fft = 1;                        // HMG_PRUNED_FFT=0: long grids go to rocFFT as before round 4
     int fused_max_m = 6144;                        // HMG_FUSED_MAX_M: longest packed row the one-row-in-LDS kernel takes
+    int fused_prefer_m = 2500;                     // HMG_FUSED_PREFER_M: above this the long-grid route is tried first
     int pruned_lp_min = 0;                         // HMG_PRUNED_LP_MIN: smallest sub-transform length to consider
     int use_chirp = 1;                             // HMG_CHIRP=0: every row of a long grid takes the decomposition
     std::map<std::tuple<int, int, int>, ChirpPlan> chirp;   // (nxs, LP, p0) -> tables
@@ -2743,6 +2744,7 @@ static int ctx_init(hmg_ctx* c, int device) {
     if (const char* s = getenv("HMG_FUSED_FFT")) c->use_fused_fft = atoi(s);
     if (const char* s = getenv("HMG_PRUNED_FFT")) c->use_pruned_fft = atoi(s);
     if (const char* s = getenv("HMG_FUSED_MAX_M")) c->fused_max_m = atoi(s);
+    if (const char* s = getenv("HMG_FUSED_PREFER_M")) c->fused_prefer_m = atoi(s);
     if (const char* s = getenv("HMG_PRUNED_LP_MIN")) c->pruned_lp_min = atoi(s);
     if (const char* s = getenv("HMG_CHIRP")) c->use_chirp = atoi(s);
     HIP_TRY(hipMalloc((void**)&c->d_fault, sizeof(int)));
@@ -3638,7 +3640,11 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
     if (c->use_fused_fft && xs_aligned) {
         FusedPlan* FP = nullptr;
         if (get_fused_plan(c, nxs, &FP)) return 1;
-        if (!FP && c->use_pruned_fft) {
+        // Rows longer than M = 2500 that would still fit LDS as one row (run-time plan, one or two workgroups per CU) are
+        // faster on the long-grid route when it applies - Config-3 grid, profile stage, nxs = 6000 / 8000 / 12000: 0.465 /
+        // 0.551 / 0.976 ms as one row against 0.342 / 0.400 / 0.438 ms (tools/probes/mid_length_routes.py)
+        const bool prefer_long = FP && FP->plan.M > c->fused_prefer_m;
+        if ((!FP || prefer_long) && c->use_pruned_fft) {
             // a grid too long for one LDS row: the pruned decomposition, if the support of the rows is short enough
             FusedArgs A{};
             A.nxs = nxs; A.nm = nm; A.nk = nk; A.do_norm = do_mass_norm;
