@@ -91,12 +91,27 @@ int main() { std::vector<double> x(4097), o(4097); for (int i = 0; i < 4097; ++i
         body = """
 extern "C" int ldsfft_rfft_imag(const double*, int, int, double*);
 extern "C" int ldsfft_rfft_imag_spec2500(const double*, int, int, double*);
+extern "C" int ldsfft_pruned_rfft_imag(const double*, int, int, int, int, double*);
+extern "C" int ldsfft_chirp_rfft_imag(const double*, int, int, int, int, int, int, double*);
 int main() { int rc = 0; for (int n : {4, 12, 600, 5000, 20000}) { std::vector<double> y(n), o(n / 2 + 1);
   for (int i = 0; i < n; ++i) y[i] = 1.0 / (1 + i); rc |= ldsfft_rfft_imag(y.data(), n, 512, o.data()); }
   // the compile-time plan's sequences: 3-of-5 butterflies on the compact source, full ones on it, all five passes
   for (int nz_from : {1, 375, 376, 625, 626, 2500}) { std::vector<double> y(5000, 0.0), o(2501);
     for (int i = 0; i < 2 * nz_from && i < 5000; ++i) y[i] = 1.0 / (1 + i);
     rc |= ldsfft_rfft_imag_spec2500(y.data(), nz_from, 512, o.data()); }
+  // the long-grid routes (round 4): residue pairs of the pruned decomposition (odd and even R, mirrors needed or not)
+  // and the chirp route with and without one-sided windows; buffers sized exactly, so any stray index trips ASan
+  struct P { int n, LP, nz, jn; };
+  for (P c : {P{30000, 1000, 1640, 394}, P{30000, 1000, 2000, 15000}, P{40000, 1250, 2400, 9000}, P{8000, 2000, 1, 1999},
+              P{32768, 2048, 4000, 8191}, P{30000, 1500, 3000, 53}}) {
+    std::vector<double> y(c.n, 0.0), o(c.n / 2 + 1);
+    for (int i = 0; i < c.nz; ++i) y[i] = 1.0 / (1 + i);
+    rc |= ldsfft_pruned_rfft_imag(y.data(), c.n, c.LP, 512, c.jn, o.data()); }
+  struct Q { int n, LP, p0, nwin, jn; };
+  for (Q c : {Q{30000, 1000, 820, 0, 590}, Q{30000, 1000, 820, 2, 2952}, Q{40000, 1250, 1216, 1, 1900}, Q{30000, 1000, 1000, 0, 0}}) {
+    std::vector<double> y(c.n, 0.0), o(c.n / 2 + 1);
+    for (int i = 0; i < 2 * c.p0; ++i) y[i] = 1.0 / (1 + i);
+    rc |= ldsfft_chirp_rfft_imag(y.data(), c.n, c.LP, c.p0, c.nwin, 512, c.jn, o.data()); }
   return rc; }"""
     main.write_text("#include <vector>\n" + body)
     exe = tmp_path / "san"
