@@ -240,7 +240,22 @@ int hmg_profile_rows_from_mvir(hmg_ctx* ctx, int kind, int nz, int nm, const dou
  * fft_step = (xs[-1]-xs[0])/nxs (hmvec/fft.py:45-47).  d_kts must be that uniform mode grid,
  * kts[j] = j * kts[1]: the in-LDS transform forms 1/kt_j as (1/j) / kt_1 and brackets the target
  * wavenumbers by division with the mode spacing.
- * out[z,m,k] *= d_post[z,m] if d_post != NULL (pressure prefactor, hmvec.py:316).          */
+ * out[z,m,k] *= d_post[z,m] if d_post != NULL (pressure prefactor, hmvec.py:316).
+ *
+ * Routes (chosen by the library from the radial grid and the rows' support; same results to <= 1e-12 in u):
+ *   nxs = 1000, 2000, 4000, 5000      one (z,m) row per workgroup, packed-real FFT in LDS, compile-time plan;
+ *   other even nxs <= 5000 whose half factors into 2, 3, 4, 5: the same with a run-time plan;
+ *   longer grids - the ones the reference's own callers use: add_battaglia_profile(xmax=50, nxs=30000)
+ *     (examples/lensing_baryons.py:27, bin/tests.py:308), numeric NFW nxs=40000 / xmax=200 (hmvec/params.py:59-60) -
+ *     whose half is a multiple of a compiled sub-transform length LP >= the rows' support (profiles are cut at
+ *     cmax << xmax): the long-grid kernels (R = nxs/2/LP pairs of length-LP transforms in LDS, or the chirp transform
+ *     for rows that need few modes).  An EAGER call measures the support bound of its rows (one small kernel, a
+ *     4-byte copy, one stream synchronisation); inside a captured step the bound of the last eager call on the same
+ *     arrays is used and every row re-checks itself: a row beyond the bound is filled with NaN and the next
+ *     synchronising call (hmg_sync, hmg_memcpy_d2h) returns an error;
+ *   everything else (odd nxs, other prime factors, supports that do not prune): integrand -> rocFFT R2C -> interpolation.
+ * Environment switches for testing, read at hmg_ctx_create: HMG_FUSED_FFT=0 (rocFFT for everything), HMG_PRUNED_FFT=0,
+ * HMG_CHIRP=0, HMG_PRUNED_LP_MIN, HMG_FUSED_MAX_M, HMG_FUSED_PREFER_M.                                              */
 int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_step,
                     const double* d_xs, const double* d_kts,
                     const double* d_amp, const double* d_xc, const double* d_alpha,
