@@ -42,7 +42,7 @@ def rendezvous_path(tag, world):
     the launcher's PID (all ranks of one launch share it as parent) and, under an elastic
     launcher, the restart count - so a restarted group never reads its predecessor's id."""
     restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-    named = os.environ.get("HMG_LAUNCH_TAG") or os.environ.get("TORCHELASTIC_RUN_ID")
+    named = _launch_name()
     who = "named" if named else f"pp{os.getppid()}"       # (the file NAME only has to be common to the ranks; the
     name = f"hmg_rdzv_{tag}_w{world}_{who}_r{restart}"     # nonce inside it is what identifies the launch)
     return os.path.join(os.environ.get("HMG_RDZV_DIR", "/tmp"), name)
@@ -58,13 +58,24 @@ def _parent_start_ticks():
         return "0"
 
 
+def _launch_name():
+    """The name the launcher gave this launch, if it gave one that identifies it: HMG_LAUNCH_TAG, or torchrun's
+    TORCHELASTIC_RUN_ID unless that is its default ("none" - the same for every launch that does not pass --rdzv-id,
+    so a crashed earlier launch on the same port would share it)."""
+    tag = os.environ.get("HMG_LAUNCH_TAG")
+    if tag:
+        return tag
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    return run_id if run_id not in ("", "none") else None
+
+
 def launch_identity(tag, world):
     """Text that every rank of THIS launch knows and no earlier launch could have written.  A launcher that
     names the launch says so: HMG_LAUNCH_TAG, or torchrun's TORCHELASTIC_RUN_ID (with the restart count) - these
     hold whatever sits between the launcher and the ranks (a per-rank wrapper script gives every rank a different
     parent).  Only when neither is set does the identity fall back on the parent process: its PID and start time."""
     restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-    named = os.environ.get("HMG_LAUNCH_TAG") or os.environ.get("TORCHELASTIC_RUN_ID")
+    named = _launch_name()
     who = f"id:{named}" if named else f"pp{os.getppid()}@{_parent_start_ticks()}"
     return f"{tag}|w{world}|{who}|r{restart}"
 

@@ -120,5 +120,7 @@ def test_launch_identity_survives_wrappers_and_long_tags(monkeypatch):
     monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run-" + "x" * 299 + "y")   # differs only beyond byte 96 of the text
     assert dist.launch_nonce("29500_x", 2) != a
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")              # torchrun's default names nothing: parent identity
+    assert f"pp{os.getppid()}" in dist.launch_identity("29500_x", 2)
     monkeypatch.setenv("HMG_LAUNCH_TAG", "mine")                    # the explicit tag wins
     assert "id:mine" in dist.launch_identity("29500_x", 2)
