@@ -3555,7 +3555,8 @@ static int profile_support(hmg_ctx* c, int rows, int nxs, const double* xs, cons
     int h = 0;
     HIP_TRY(hipMemcpyAsync(&h, d_p0, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->support[key] = h;
+    if (c->support.size() >= 256) c->support.clear();     // (keyed by addresses: bounded, and a dropped entry only costs
+    c->support[key] = h;                                   //  a captured step its bound - the eager call before it refills)
     *p0max = h;
     return 0;
 }
