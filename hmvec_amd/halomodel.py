@@ -372,6 +372,13 @@ class HaloModel(Cosmology):
             ctx.call_now("hmg_nfw_analytic", nz, nm, nk, nfw_alone.d_cs, nfw_alone.d_rs, nfw_alone.d_zs, nfw_alone.d_ks,
                          nfw_alone.d_nfw_series, nfw_alone.d_uk)
         if "fft" in st or hod_sums:
+            if "chain_alone" in x and "fft" in st and (hod_sums or prep is not None):
+                # experiment: the per-z chain as a launch of its own in front of the stand-alone
+                # row kernel (no private segment) instead of a role of the profile group
+                ctx.call_now("hmg_group_profile", nz, nm, nk, None, ref("hod") if hod_sums else None,
+                             C.byref(prep) if prep is not None else None)
+                ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), None, None)
+                return prep is not None
             ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), ref("hod") if hod_sums else None,
                          C.byref(prep) if prep is not None else None)
             return prep is not None
