@@ -45,10 +45,13 @@ def test_ragged_grid_sizes(nz, nm, nk):
     assert ok
 
 
-@pytest.mark.parametrize("nxs", [16, 30, 100, 600, 14, 45, 22, 25000])
+@pytest.mark.parametrize("nxs", [16, 30, 100, 600, 14, 45, 22, 25000, 5400, 6000, 7000, 12288])
 def test_fft_lengths_fused_and_fallback(nxs):
     """16, 30, 100, 600: workgroup FFT (radix 5/4/3/2, incl. an odd half-length); 14, 22: prime
-    factor 7/11 -> rocFFT; 45: odd length -> rocFFT; 25000: too long for LDS -> rocFFT."""
+    factor 7/11 -> rocFFT; 45: odd length -> rocFFT; 25000: too long for LDS -> the long-grid route (10 x 1250);
+    6000: fits LDS as one row but is longer than M = 2500 -> the long-grid route first (3 x 1000); 5400: longer than
+    M = 2500 with no compiled sub-transform length as a divisor -> one row in LDS, run-time plan; 7000: factor 7 ->
+    rocFFT; 12288: the longest one-row length (M = 6144 = 3 x 2048 -> the long-grid route)."""
     import hmvec_amd as hm
     zs = np.array([0.3, 1.4])
     ms = np.geomspace(1e12, 1e15, 6)
