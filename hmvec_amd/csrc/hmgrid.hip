@@ -120,9 +120,10 @@ struct hmg_ctx {
     int fused_prefer_m = 2500;                     // HMG_FUSED_PREFER_M: above this the long-grid route is tried first
     int pruned_lp_min = 0;                         // HMG_PRUNED_LP_MIN: smallest sub-transform length to consider
     int use_chirp = 1;                             // HMG_CHIRP=0: every row of a long grid takes the decomposition
+    int use_band_fft = 1;                          // HMG_BAND_FFT=0: supports that do not prune go to rocFFT
     std::map<std::tuple<int, int, int>, ChirpPlan> chirp;   // (nxs, LP, p0) -> tables
     std::map<int, PrunedPlan> pruned;              // nxs -> tables of the pruned long-grid route
-    std::map<SupportKey, int> support;             // last measured support bound (packed samples) of a launch's rows
+    std::map<SupportKey, std::pair<int, int>> support;   // last measured bounds of a launch's rows: (support in packed samples, needed modes)
     int* d_fault = nullptr;                        // device word a kernel raises when it cannot do what it was launched for
     int* h_fault = nullptr;                        // its pinned host twin
     bool fault_armed = false;                      // a kernel that may raise it ran since the last check
@@ -2747,6 +2748,7 @@ static int ctx_init(hmg_ctx* c, int device) {
     if (const char* s = getenv("HMG_FUSED_PREFER_M")) c->fused_prefer_m = atoi(s);
     if (const char* s = getenv("HMG_PRUNED_LP_MIN")) c->pruned_lp_min = atoi(s);
     if (const char* s = getenv("HMG_CHIRP")) c->use_chirp = atoi(s);
+    if (const char* s = getenv("HMG_BAND_FFT")) c->use_band_fft = atoi(s);
     HIP_TRY(hipMalloc((void**)&c->d_fault, sizeof(int)));
     HIP_TRY(hipMemset(c->d_fault, 0, sizeof(int)));
     HIP_TRY(hipHostMalloc((void**)&c->h_fault, sizeof(int), hipHostMallocDefault));
@@ -3540,24 +3542,29 @@ static int get_chirp_plan(hmg_ctx* c, int nxs, int LP, int p0, ChirpPlan** out) 
 // Support bound of a launch's rows in packed samples.  Eager calls measure it (one small kernel, a 4-byte copy);
 // inside a captured step the value of the last eager call with the same arrays is used - what a replay computes
 // is what was captured - and the kernel itself re-checks every row (fault word).
-static int profile_support(hmg_ctx* c, int rows, int nxs, const double* xs, const double* cmax, int* p0max) {
-    const SupportKey key{cmax, xs, rows, nxs};
+static int profile_support(hmg_ctx* c, int rows, const FusedArgs& A, int* p0max, int* jnmax) {
+    const SupportKey key{A.cmax, A.xs, rows, A.nxs};
     if (c->capturing) {
         auto it = c->support.find(key);
         REQUIRE(it != c->support.end(), "profile support bound unknown inside a captured step: run the step once eagerly first");
-        *p0max = it->second;
+        *p0max = it->second.first;
+        *jnmax = it->second.second;
         return 0;
     }
     if (ensure_scratch(c, 2, 64)) return 1;
     int* d_p0 = (int*)c->scratch[2];
-    HIP_TRY(hipMemsetAsync(d_p0, 0, sizeof(int), c->stream));
-    HIP_TRY((hipError_t)launch_profile_support(c->stream, rows, nxs, xs, cmax, d_p0));
-    int h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, d_p0, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(d_p0, 0, 2 * sizeof(int), c->stream));
+    // (the needed modes are only bounded when the target grid is ascending - the promise of the hint arrays)
+    HIP_TRY((hipError_t)launch_profile_support(c->stream, rows, A.nxs, A.xs, A.cmax, A.nconst ? A.rss : nullptr, A.zs, A.nm,
+                                               A.kts, A.ks, A.nk, d_p0));
+    int h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, d_p0, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!A.nconst) h[1] = A.nxs / 2;
     if (c->support.size() >= 256) c->support.clear();     // (keyed by addresses: bounded, and a dropped entry only costs
-    c->support[key] = h;                                   //  a captured step its bound - the eager call before it refills)
-    *p0max = h;
+    c->support[key] = std::make_pair(h[0], h[1]);          //  a captured step its bounds - the eager call before it refills)
+    *p0max = h[0];
+    *jnmax = h[1];
     return 0;
 }
 
@@ -3569,8 +3576,8 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
     bool any = false;
     for (int lp : PRUNED_LP) any = any || (M % lp == 0 && M / lp >= 2);
     if (!any) return 0;
-    int p0max = 0;
-    if (profile_support(c, rows, nxs, A0.xs, A0.cmax, &p0max)) return 1;
+    int p0max = 0, jnmax = 0;
+    if (profile_support(c, rows, A0, &p0max, &jnmax)) return 1;
     int LP = 0;
     const int lp_min = c->pruned_lp_min > p0max ? c->pruned_lp_min : p0max;     // (HMG_PRUNED_LP_MIN: tuning / tests)
     for (int lp : PRUNED_LP)
@@ -3578,7 +3585,31 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
     if (!LP)
         for (int lp : PRUNED_LP)
             if (M % lp == 0 && M / lp >= 2 && lp >= p0max) { LP = lp; break; }
-    if (!LP) return 0;                                   // support too long (e.g. tSZ pressure at xmax = 2): rocFFT
+    if (!LP) {
+        // The support does not prune (the tSZ notebook's pressure profile at xmax = 2).  If every row needs few modes
+        // the narrow-band route takes the launch: D = M / LB transforms of length LB >= 2 jn + 2 of the decimated
+        // rows (longgrid.hip); otherwise rocFFT.
+        if (!c->use_band_fft || !A0.nconst) return 0;
+        int LB = 0;
+        for (int lb : {1000, 1024, 1250})
+            if (M % lb == 0 && band_lb_compiled(lb) && 2 * jnmax + 2 <= lb) { LB = lb; break; }
+        if (!LB) return 0;
+        PrunedPlan* PP = nullptr;
+        FusedPlan* FL = nullptr;
+        if (get_pruned_plan(c, nxs, &PP)) return 1;
+        if (get_fused_plan(c, 2 * LB, &FL)) return 1;
+        REQUIRE(FL != nullptr, "no twiddle table for the band transform length");
+        PrunedArgs G{};
+        G.F = A0;
+        G.F.twN = PP->twN;
+        G.M = M; G.R = M / LB; G.twB = PP->twB; G.twL = FL->twM; G.u = nullptr; G.fault = c->d_fault; G.row0 = 0;
+        int stop = -1;
+        if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
+        HIP_TRY((hipError_t)launch_band(c->stream, LB, G, rows, jnmax));
+        c->fault_armed = true;
+        *taken = 1;
+        return bracket_close(c, stop);
+    }
     PrunedPlan* PP = nullptr;
     FusedPlan* FL = nullptr;
     if (get_pruned_plan(c, nxs, &PP)) return 1;

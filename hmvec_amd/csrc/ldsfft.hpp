@@ -463,4 +463,16 @@ HMG_HD double chirp_unpack(const cplx* Y, int Lc, int j, cplx chj, const UnpackT
     return fa;
 }
 
+// ---- Rows whose support does NOT prune but which need few modes: the narrow-band route (the tSZ notebook's
+// add_battaglia_pres_profile(xmax=2, nxs=30000): the profile fills half the grid and more, while the halo scale R_200c
+// and xmax = 2 put every needed mode below j ~ 250 of 15000).  Decimation in time with the OUTPUT pruned: with
+// p = p1 + D p2, M = D LB,
+//     Z[j] = sum_{p1 < D} W_M^{j p1} Y_p1[j mod LB],      Y_p1 = FFT_LB(z[p1 + D p2], p2 < LB),
+// - D transforms of length LB >= 2 jn + 2 of the decimated row, of which only the outputs at the two ends are needed
+// (the last pass's pruning), accumulated per needed mode with a running twiddle W_M^{j p1} = (W_M^j)^{p1}.  Nothing
+// of length M is ever held: one length-LB buffer in LDS, one accumulator per mode in registers.
+// The owner of accumulator slot t (0 <= t < 2 jn + 1) holds mode j = t - jn and reads Y at j mod LB:
+HMG_HD int band_mode(int t, int jn) { return t - jn; }
+HMG_HD int band_index(int j, int LB) { return j < 0 ? LB + j : j; }
+
 }  // namespace hmg

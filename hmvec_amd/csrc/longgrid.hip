@@ -310,12 +310,224 @@ __global__ __launch_bounds__(NT, pruned_occ<LP>()) void profile_pruned_kernel(Pr
     profile_pruned_row<NT, LP>(G, G.row0 + blockIdx.x, smem);
 }
 
+// ---- Rows whose support does not prune but which need few modes: the narrow-band route (ldsfft.hpp).  The tSZ notebook
+// of the reference (examples/tSZ example.ipynb: add_battaglia_pres_profile("y", family="pres", xmax=2, nxs=30000)) is
+// the case: with xmax = 2 the pressure profile fills half the grid and more - nothing to prune on the input side, the
+// pruned decomposition does not apply - while r_s = R_200c and the coarse mode spacing 2 pi / 2 put every needed mode
+// below j ~ 250 of 15000.  One workgroup per (z,m) row; per residue p1 < D of the sample index: the decimated row's
+// first pass straight from the integrand (the thread that owns the inputs of butterfly j evaluates them), the other
+// passes of the length-LB plan in LDS with the last one pruned to the band, and one multiply-add per needed mode into
+// a register accumulator with the running twiddle (W_M^j)^{p1}.  Every sample is evaluated exactly once; the modes
+// never leave the CU (u_j sits in LDS for the interpolation, as in the one-row kernel).  G.R is D here.
+template <int NT, int LB, int MAXA>
+__device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, double* smem) {
+    const FusedArgs& A = G.F;
+    // dynamic LDS: [0, LB) cplx = the transform buffer (later the band's modes), then LB/2 doubles of u_j, then 32
+    // doubles of scalars laid out as in profile_fused_row
+    cplx* buf = reinterpret_cast<cplx*>(smem);
+    double* us = smem + 2 * (size_t)LB;
+    double* red = us + LB / 2 + (LB / 2 & 1);
+    int* s_cnt = reinterpret_cast<int*>(red + 17);
+    int* s_jn = reinterpret_cast<int*>(red + 18);
+    using S0 = SubPass<LB, 0>;
+    constexpr int R0 = S0::R, nb0 = S0::nb, MAXB0 = (nb0 + NT - 1) / NT;
+    // MAXA: accumulator slots per thread; 2 jn + 1 <= MAXA NT of them are in use (the launch picks 1 when the bound on
+    // the needed modes allows: 24 registers fewer)
+    constexpr int nb_last = SubPass<LB, S0::P.npass - 1>::nb;
+    static_assert(S0::Ns == 1, "first pass");
+    const int M = G.M, D = G.R, nxs = 2 * M;
+    const double Aamp = A.amp ? A.amp[row] : A.amp_c;
+    const double XC = A.xc ? A.xc[row] : A.xc_c;
+    const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
+    const double EX = A.expo ? A.expo[row] : A.expo_c;
+    const double cm = A.cmax[row];
+    const double ln_xc = (A.xc == nullptr && A.xc_c == 1.0) ? 0.0 : log_fast(XC);
+    const int z = row / A.nm;
+    double* __restrict__ dst = A.out + (size_t)row * A.nk;
+    // row scalars and the end of the left-fill prefix: the last wavefront, as in profile_fused_row (hints are a
+    // precondition of this route: without them every mode is needed and the launch would not have come here)
+    if (threadIdx.x >= NT - 64) {
+        const int lane = threadIdx.x & 63;
+        const double isc0 = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));
+        const double klo0 = A.kts[1] * isc0;
+        const double idk0 = 1.0 / klo0;
+        int jn0 = M, nleft = 0;
+        if (A.nconst) {
+            const double tmax = A.ks[A.nk - 1] * idk0;
+            if (tmax < (double)(M - 4)) jn0 = (int)tmax + 3;
+            int base = 0, end = A.nk;
+            for (;;) {
+                const int stp = (end - base + 63) >> 6;
+                const int first = base + lane * stp;
+                bool below = false;
+                if (first < end) {
+                    const int last = first + stp - 1;
+                    below = A.ks[last < end ? last : end - 1] < klo0;
+                }
+                base += __popcll(__ballot(below)) * stp;
+                if (base >= end) { base = end; break; }
+                if (stp == 1) break;
+                end = base + stp < end ? base + stp : end;
+            }
+            nleft = base;
+        }
+        if (lane == 0) {
+            *s_cnt = nleft;
+            *s_jn = jn0;
+            red[19] = isc0; red[20] = klo0; red[21] = A.kts[M] * isc0; red[22] = idk0;
+            red[23] = 1.0 / A.kts[1];
+        }
+    }
+    __syncthreads();
+    const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
+    // The launch was sized from a bound on the needed modes (profile_support); a row beyond it cannot be done here: NaN
+    // and the context's fault word, as for the support bound of the pruned route.
+    if (2 * jn + 2 > LB || 2 * jn + 1 > MAXA * NT) {
+        for (int i = threadIdx.x; i < A.nk; i += NT) dst[i] = __builtin_nan("");
+        if (threadIdx.x == 0) {
+            atomicOr(G.fault, 1);
+            if (A.nconst) { A.nconst[row] = 0; A.cconst[row] = __builtin_nan(""); }
+        }
+        return;
+    }
+    const int nslot = 2 * jn + 1;
+    cplx acc[MAXA], wcur[MAXA], wstep[MAXA];
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) {
+        const int t = threadIdx.x + a * NT;
+        acc[a] = cplx{0.0, 0.0};
+        wcur[a] = cplx{1.0, 0.0};
+        const int j = band_mode(t, jn);
+        wstep[a] = t < nslot ? G.twB[j < 0 ? M + j : j] : cplx{1.0, 0.0};        // W_M^j
+    }
+    const int keep = (2 * jn + 2 < nb_last) ? jn : -1;
+    double nrm = 0.0;
+    for (int p1 = 0; p1 < D; ++p1) {
+        // first pass (radix R0, sub-transform size 1) of the decimated row z[p1 + D p2], straight from the integrand
+#pragma unroll
+        for (int b = 0; b < MAXB0; ++b) {
+            const int jb = threadIdx.x + b * NT;
+            if (jb < nb0) {
+                cplx v[R0];
+#pragma unroll
+                for (int t = 0; t < R0; ++t) {
+                    const int j = 2 * (p1 + D * (jb + t * nb0));
+                    const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
+                    double r0 = 0.0, r1 = 0.0;
+                    if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
+                    if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+                    v[t] = cplx{xv.x * r0, xv.y * r1};
+                    if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
+                        const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
+                        nrm += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
+                    }
+                }
+                dft_small<R0>(v);
+#pragma unroll
+                for (int t = 0; t < R0; ++t) buf[jb * R0 + t] = v[t];
+            }
+        }
+        __syncthreads();
+        pruned_passes<NT, LB, 1, 1>(buf, G.twL, 1, keep);
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) {
+            const int t = threadIdx.x + a * NT;
+            if (t < nslot) {
+                acc[a] = cadd(acc[a], cmul(buf[band_index(band_mode(t, jn), LB)], wcur[a]));
+                wcur[a] = cmul(wcur[a], wstep[a]);
+            }
+        }
+        __syncthreads();                                       // the next residue's first pass overwrites the buffer
+    }
+    // mass norm (the order of the partial sums differs from the one-row kernel: per thread over its samples of all
+    // residues, then wavefronts in order) and the scale of the unpack step
+    {
+        const double ws = wave_sum(nrm);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+    }
+    // the band's modes to LDS: slot t = mode t - jn
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) {
+        const int t = threadIdx.x + a * NT;
+        if (t < nslot) buf[t] = acc[a];
+    }
+    __syncthreads();
+    double tot = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) tot += red[w];
+    const double sc = -A.step / (A.do_norm ? tot : 1.0) * red[23];
+    for (int j = 1 + (int)threadIdx.x; j <= jn; j += NT) {
+        const UnpackTw w = A.twN[j];
+        double fa, fb;
+        unpack_imag_pair(buf[jn + j], buf[jn - j], w.co, w.si, fa, fb);
+        us[j - 1] = fa * sc * w.rj;
+    }
+    __syncthreads();
+    // ---- interpolation: as profile_fused_row, the modes read from LDS (targets beyond mode jn - 2 do not exist:
+    // jn = floor(max(ks)/k_lo) + 3)
+    const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
+    const double pf = A.post ? A.post[row] : 1.0;
+    const double u1 = us[0];
+    const int nleft = __builtin_amdgcn_readfirstlane(*s_cnt);
+    if (nleft > 0) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const double c = u1 * pf;
+        const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+        const int npair = (nleft - head) >> 1;
+        v2d* __restrict__ d2 = reinterpret_cast<v2d*>(dst + head);
+        const v2d cc = {c, c};
+        for (int q = threadIdx.x; q < npair; q += NT) __builtin_nontemporal_store(cc, &d2[q]);
+        if (threadIdx.x == 0) {
+            if (head) __builtin_nontemporal_store(c, &dst[0]);
+            if ((nleft - head) & 1) __builtin_nontemporal_store(c, &dst[nleft - 1]);
+        }
+    }
+    for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
+        if (i < nleft) continue;
+        const double k = A.ks[i];
+        double val = 0.0;
+        if (!(k > k_hi)) {
+            int j = (int)(k * inv_dk);
+            j = j < 1 ? 1 : (j > jn - 1 ? jn - 1 : j);
+            const double fr = fma(k, inv_dk, -(double)j);
+            const double y0 = us[j - 1], y1 = us[j];
+            val = fma(y1 - y0, fr, y0);
+        }
+        __builtin_nontemporal_store(val * pf, &dst[i]);
+    }
+    if (threadIdx.x == 0) {
+        A.nconst[row] = nleft;
+        A.cconst[row] = u1 * pf;
+    }
+}
+#ifndef HMG_BAND_OCC
+#define HMG_BAND_OCC 6
+#endif
+template <int NT, int LB, int MAXA>
+__global__ __launch_bounds__(NT, HMG_BAND_OCC) void profile_band_kernel(PrunedArgs G) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    profile_band_row<NT, LB, MAXA>(G, G.row0 + blockIdx.x, smem);
+}
+
 // Upper bound of the support of a launch's rows: max over rows of the number of PACKED samples that can be non-zero,
 // ceil(#{n : x_n <= cmax[row]} / 2) (xs increasing; the mask of hmvec/fft.py:81 is strict, |x| > cmax).
+// out[1]: the largest needed mode of the launch, jn = floor(max(ks)/k_lo) + 3 exactly as the row kernels form it (ks
+// ascending: the promise that comes with the hint arrays; without it out[1] stays 0 and means "every mode").
 __global__ void profile_support_kernel(int rows, int nxs, const double* __restrict__ xs, const double* __restrict__ cmax,
+                                       const double* __restrict__ rss, const double* __restrict__ zs, int nm,
+                                       const double* __restrict__ kts, const double* __restrict__ ks, int nk,
                                        int* __restrict__ out) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    int p0 = 0;
+    int p0 = 0, jn = 0;
+    if (row < rows && rss != nullptr) {
+        const double isc0 = 1.0 / (rss[row] * (1.0 + zs[row / nm]));
+        const double klo0 = kts[1] * isc0;
+        const double idk0 = 1.0 / klo0;
+        const double tmax = ks[nk - 1] * idk0;
+        jn = tmax < (double)(nxs / 2 - 4) ? (int)tmax + 3 : nxs / 2;
+    }
+    for (int off = 32; off; off >>= 1) jn = max(jn, __shfl_xor(jn, off));
+    if ((threadIdx.x & 63) == 0 && jn > 0) atomicMax(out + 1, jn);
     if (row < rows) {
         const double cm = cmax[row];
         int lo = 0, hi = nxs;                       // first n with xs[n] > cm
@@ -366,10 +578,31 @@ int launch_pruned(hipStream_t stream, int LP, PrunedArgs G, int rows, size_t row
     return (int)hipErrorInvalidValue;
 }
 
-int launch_profile_support(hipStream_t stream, int rows, int nxs, const double* xs, const double* cmax, int* d_out) {
+int launch_profile_support(hipStream_t stream, int rows, int nxs, const double* xs, const double* cmax, const double* rss,
+                           const double* zs, int nm, const double* kts, const double* ks, int nk, int* d_out) {
     hipLaunchKernelGGL(profile_support_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, rows, nxs, xs,
-                       cmax, d_out);
+                       cmax, rss, zs, nm, kts, ks, nk, d_out);
     return (int)hipGetLastError();
+}
+
+template <int LB>
+static int launch_band_lb(hipStream_t stream, PrunedArgs G, int rows, int jnmax) {
+    const size_t lds = (size_t)LB * 16 + (size_t)(LB / 2 + 2) * 8 + 32 * sizeof(double);
+    if (2 * jnmax + 1 <= FUSED_NT)
+        hipLaunchKernelGGL((profile_band_kernel<FUSED_NT, LB, 1>), dim3(rows), dim3(FUSED_NT), lds, stream, G);
+    else
+        hipLaunchKernelGGL((profile_band_kernel<FUSED_NT, LB, (LB + FUSED_NT - 1) / FUSED_NT>), dim3(rows), dim3(FUSED_NT), lds,
+                           stream, G);
+    return (int)hipGetLastError();
+}
+bool band_lb_compiled(int LB) { return LB == 1000 || LB == 1024 || LB == 1250; }
+int launch_band(hipStream_t stream, int LB, PrunedArgs G, int rows, int jnmax) {
+    switch (LB) {
+        case 1000: return launch_band_lb<1000>(stream, G, rows, jnmax);
+        case 1024: return launch_band_lb<1024>(stream, G, rows, jnmax);
+        case 1250: return launch_band_lb<1250>(stream, G, rows, jnmax);
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 }  // namespace hmg

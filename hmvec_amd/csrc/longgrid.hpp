@@ -25,7 +25,12 @@ struct PrunedArgs {
 bool pruned_lp_compiled(int LP);
 // rows [0, rows) of G in launches of at most rows_per_launch rows (the scratch line block G.u holds that many)
 int launch_pruned(hipStream_t stream, int LP, PrunedArgs G, int rows, size_t rows_per_launch);
-// *d_out = max over rows of the packed samples that can be non-zero (d_out must be zero before)
-int launch_profile_support(hipStream_t stream, int rows, int nxs, const double* xs, const double* cmax, int* d_out);
+// d_out[0] = max over rows of the packed samples that can be non-zero, d_out[1] = max over rows of the needed modes jn
+// (rss == nullptr: left 0); both must be zero before
+int launch_profile_support(hipStream_t stream, int rows, int nxs, const double* xs, const double* cmax, const double* rss,
+                           const double* zs, int nm, const double* kts, const double* ks, int nk, int* d_out);
+// the narrow-band route: transform lengths LB that are compiled in; G.R is D = M / LB, G.twL the table of length LB
+bool band_lb_compiled(int LB);
+int launch_band(hipStream_t stream, int LB, PrunedArgs G, int rows, int jnmax /* bound on the rows' needed modes */);
 
 }  // namespace hmg

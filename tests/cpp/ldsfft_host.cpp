@@ -270,3 +270,61 @@ extern "C" int ldsfft_chirp_window(int n, int LP, int p0, int nwin) {
     const ChirpTables T = chirp_make_tables(n / 2, 2 * LP, p0, nwin);
     return T.Jw + T.nwin * T.Kp;
 }
+
+// The narrow-band route (ldsfft.hpp, "Rows whose support does NOT prune"), sequenced as profile_band_kernel sequences
+// it: per residue p1 of the sample index the first pass from the samples a thread owns (p2 = j + t LB/R0), the other
+// passes of the length-LB plan (last one pruned to the band), the accumulation with the running twiddle; unpack.
+template <int LB>
+static int band_rfft_imag(const double* y, int n, int nthreads, int jn, double* imF) {
+    using S0 = SubPass<LB, 0>;
+    const int M = n / 2;
+    if (n % 2 || M % LB) return 2;
+    const int D = M / LB;
+    if (2 * jn + 2 > LB) return 5;
+    const long double twopi = 6.283185307179586476925286766559L;
+    std::vector<cplx> twB(M), twL(LB), buf(LB, cplx{1.0e30, -1.0e30});
+    for (int t = 0; t < M; ++t) twB[t] = {(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
+    for (int t = 0; t < LB; ++t) twL[t] = {(double)cosl(twopi * t / LB), (double)-sinl(twopi * t / LB)};
+    const int nacc = 2 * jn + 1;
+    std::vector<cplx> acc(nacc, cplx{0.0, 0.0}), wcur(nacc, cplx{1.0, 0.0}), wstep(nacc);
+    for (int t = 0; t < nacc; ++t) {
+        const int j = band_mode(t, jn);
+        wstep[t] = twB[((j % M) + M) % M];
+    }
+    constexpr int nb_last = SubPass<LB, S0::P.npass - 1>::nb;
+    const int keep = (2 * jn + 2 < nb_last) ? jn : -1;
+    for (int p1 = 0; p1 < D; ++p1) {
+        for (int jb = 0; jb < S0::nb; ++jb) {
+            cplx v[S0::R];
+            for (int t = 0; t < S0::R; ++t) {
+                const int p = p1 + D * (jb + t * S0::nb);
+                v[t] = cplx{y[2 * p], y[2 * p + 1]};
+            }
+            dft_small<S0::R>(v);
+            for (int t = 0; t < S0::R; ++t) buf[jb * S0::R + t] = v[t];
+        }
+        run_single_passes<LB, 1>(buf, twL, keep, nthreads);
+        for (int t = 0; t < nacc; ++t) {
+            const cplx yv = buf[band_index(band_mode(t, jn), LB)];
+            acc[t] = cadd(acc[t], cmul(yv, wcur[t]));
+            wcur[t] = cmul(wcur[t], wstep[t]);
+        }
+    }
+    for (int j = 0; j <= M; ++j) imF[j] = NAN;
+    imF[0] = 0.0;
+    for (int j = 1; j <= jn; ++j) {
+        const long double th = twopi * j / n;
+        double fa, fb;
+        unpack_imag_pair(acc[jn + j], acc[jn - j], (double)cosl(th), (double)sinl(th), fa, fb);
+        imF[j] = fa;
+    }
+    return 0;
+}
+extern "C" int ldsfft_band_rfft_imag(const double* y, int n, int LB, int nthreads, int jn, double* imF) {
+    switch (LB) {
+        case 1000: return band_rfft_imag<1000>(y, n, nthreads, jn, imF);
+        case 1024: return band_rfft_imag<1024>(y, n, nthreads, jn, imF);
+        case 1250: return band_rfft_imag<1250>(y, n, nthreads, jn, imF);
+        default: return 3;
+    }
+}

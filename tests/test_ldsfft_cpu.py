@@ -27,6 +27,9 @@ def lib(tmp_path_factory):
     lib.ldsfft_chirp_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.ldsfft_chirp_rfft_imag.restype = ctypes.c_int
+    lib.ldsfft_band_rfft_imag.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p]
+    lib.ldsfft_band_rfft_imag.restype = ctypes.c_int
     return lib
 
 
@@ -135,3 +138,23 @@ def test_chirp_route_refuses_modes_outside_its_window(lib):
     assert jw == 590 and lib.ldsfft_chirp_window(30000, 1000, 820, 2) == 590 + 2 * 1181
     assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 820, 0, 512, jw + 1, out.ctypes.data) == 5
     assert lib.ldsfft_chirp_rfft_imag(y.ctypes.data, 30000, 1000, 700, 0, 512, 10, out.ctypes.data) == 4    # support > p0
+
+
+@pytest.mark.parametrize("n,LB,nonzero,jn", [(30000, 1000, 20491, 223), (30000, 1000, 30000, 498), (30000, 1000, 12000, 1),
+                                             (30000, 1000, 25000, 0), (40000, 1250, 33333, 600), (32768, 1024, 32768, 255),
+                                             (4000, 1000, 4000, 499), (30000, 1000, 17, 300)])
+def test_narrow_band_route_matches_numpy(lib, n, LB, nonzero, jn):
+    """Rows whose support does not prune (the tSZ notebook's pressure profile fills two thirds of the grid) but which
+    need few modes: D = n/2/LB transforms of length LB of the decimated row, accumulated per mode with a running
+    twiddle, give every mode j <= jn (2 jn + 2 <= LB) - numpy's rfft to rounding."""
+    rng = np.random.default_rng(n + LB + nonzero + jn)
+    y = np.zeros(n)
+    y[:nonzero] = rng.standard_normal(nonzero) * np.exp(-np.linspace(0, 2, nonzero))
+    M = n // 2
+    out = np.zeros(M + 1)
+    assert lib.ldsfft_band_rfft_imag(y.ctypes.data, n, LB, 512, jn, out.ctypes.data) == 0
+    ref = np.fft.rfft(y)
+    scale = np.max(np.abs(ref))
+    need = np.arange(1, jn + 1)
+    assert need.size == 0 or np.max(np.abs(out[need] - ref.imag[need])) < 1e-14 * scale * np.log2(n)
+    assert lib.ldsfft_band_rfft_imag(y.ctypes.data, n, LB, 512, LB // 2, out.ctypes.data) == 5      # band too wide
