@@ -3602,7 +3602,8 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
         PrunedArgs G{};
         G.F = A0;
         G.F.twN = PP->twN;
-        G.M = M; G.R = M / LB; G.twB = PP->twB; G.twL = FL->twM; G.u = nullptr; G.fault = c->d_fault; G.row0 = 0;
+        if (ensure_scratch(c, 0, (size_t)3 * nxs * 8)) return 1;       // x, ln x, trapezoid weights in the kernel's walk order
+        G.M = M; G.R = M / LB; G.twB = PP->twB; G.twL = FL->twM; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
         int stop = -1;
         if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
         HIP_TRY((hipError_t)launch_band(c->stream, LB, G, rows, jnmax));

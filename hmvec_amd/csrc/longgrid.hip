@@ -319,6 +319,23 @@ __global__ __launch_bounds__(NT, pruned_occ<LP>()) void profile_pruned_kernel(Pr
 // passes of the length-LB plan in LDS with the last one pruned to the band, and one multiply-add per needed mode into
 // a register accumulator with the running twiddle (W_M^j)^{p1}.  Every sample is evaluated exactly once; the modes
 // never leave the CU (u_j sits in LDS for the interpolation, as in the one-row kernel).  G.R is D here.
+// The decimated rows read x_n, ln x_n and the trapezoid weights of the mass norm at a stride of D sample pairs: as they
+// lie in memory that is one 16-byte piece per 64-byte line and lane.  One small launch per profile call lays the three
+// out the way the row kernel walks them - pair (p1, p2) at [p1 LB + p2], p = p1 + D p2 - so that a wavefront's loads are
+// contiguous again (G.u holds the tables: 3 nxs doubles).  w_n = (x_{n+1} - x_{n-1})/2 with the one-sided ends of np.trapz.
+__global__ void band_tables_kernel(int nxs, int D, int LB, const double* __restrict__ xs, const double* __restrict__ logx,
+                                   double2* __restrict__ xT, double2* __restrict__ lT, double2* __restrict__ wT) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;       // q = p1 LB + p2
+    if (q >= nxs / 2) return;
+    const int p1 = q / LB, p2 = q - p1 * LB;
+    const int j = 2 * (p1 + D * p2);
+    const double x0 = xs[j], x1 = xs[j + 1];
+    const double xl = j > 0 ? xs[j - 1] : x0, xr = j + 2 < nxs ? xs[j + 2] : x1;
+    xT[q] = make_double2(x0, x1);
+    lT[q] = logx ? make_double2(logx[j], logx[j + 1]) : make_double2(log_fast(x0), log_fast(x1));
+    wT[q] = make_double2(0.5 * (x1 - xl), 0.5 * (xr - x0));
+}
+
 template <int NT, int LB, int MAXA>
 __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, double* smem) {
     const FusedArgs& A = G.F;
@@ -401,6 +418,9 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
         wstep[a] = t < nslot ? G.twB[j < 0 ? M + j : j] : cplx{1.0, 0.0};        // W_M^j
     }
     const int keep = (2 * jn + 2 < nb_last) ? jn : -1;
+    const double2* __restrict__ xT = reinterpret_cast<const double2*>(G.u);
+    const double2* __restrict__ lT = xT + M;
+    const double2* __restrict__ wT = lT + M;
     double nrm = 0.0;
     for (int p1 = 0; p1 < D; ++p1) {
         // first pass (radix R0, sub-transform size 1) of the decimated row z[p1 + D p2], straight from the integrand
@@ -411,16 +431,14 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
                 cplx v[R0];
 #pragma unroll
                 for (int t = 0; t < R0; ++t) {
-                    const int j = 2 * (p1 + D * (jb + t * nb0));
-                    const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
+                    const int q = p1 * LB + jb + t * nb0;                       // pair p = p1 + D p2, p2 = jb + t nb0
+                    const double2 xv = xT[q], lv = lT[q], wv = wT[q];
                     double r0 = 0.0, r1 = 0.0;
-                    if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
-                    if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+                    if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(lv.x - ln_xc, Aamp, AL, EX, A.gamma);
+                    if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(lv.y - ln_xc, Aamp, AL, EX, A.gamma);
                     v[t] = cplx{xv.x * r0, xv.y * r1};
-                    if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
-                        const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
-                        nrm += 0.5 * (xv.y - xl) * (r0 * (xv.x * xv.x)) + 0.5 * (xr - xv.x) * (r1 * (xv.y * xv.y));
-                    }
+                    if (A.do_norm && (r0 != 0.0 || r1 != 0.0))
+                        nrm += wv.x * (r0 * (xv.x * xv.x)) + wv.y * (r1 * (xv.y * xv.y));
                 }
                 dft_small<R0>(v);
 #pragma unroll
@@ -587,6 +605,12 @@ int launch_profile_support(hipStream_t stream, int rows, int nxs, const double* 
 
 template <int LB>
 static int launch_band_lb(hipStream_t stream, PrunedArgs G, int rows, int jnmax) {
+    const int M = G.M;
+    double2* tb = reinterpret_cast<double2*>(G.u);
+    hipLaunchKernelGGL(band_tables_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, 2 * M, G.R, LB, G.F.xs,
+                       G.F.logx, tb, tb + M, tb + 2 * (size_t)M);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
     const size_t lds = (size_t)LB * 16 + (size_t)(LB / 2 + 2) * 8 + 32 * sizeof(double);
     if (2 * jnmax + 1 <= FUSED_NT)
         hipLaunchKernelGGL((profile_band_kernel<FUSED_NT, LB, 1>), dim3(rows), dim3(FUSED_NT), lds, stream, G);

@@ -253,9 +253,13 @@ int hmg_profile_rows_from_mvir(hmg_ctx* ctx, int kind, int nz, int nm, const dou
  *     4-byte copy, one stream synchronisation); inside a captured step the bound of the last eager call on the same
  *     arrays is used and every row re-checks itself: a row beyond the bound is filled with NaN and the next
  *     synchronising call (hmg_sync, hmg_memcpy_d2h) returns an error;
- *   everything else (odd nxs, other prime factors, supports that do not prune): integrand -> rocFFT R2C -> interpolation.
+ *   long grids whose support does NOT prune but whose rows all need few modes (2 jn + 2 <= 1000..1250; the tSZ notebook's
+ *     add_battaglia_pres_profile(xmax=2, nxs=30000)): the narrow-band kernel - nxs/2/LB transforms of length LB of the
+ *     decimated row, one accumulator per needed mode; needs the hint arrays (ascending d_ks); the bound on the needed
+ *     modes is measured and re-checked like the support bound;
+ *   everything else (odd nxs, other prime factors, wide supports with many modes): integrand -> rocFFT R2C -> interpolation.
  * Environment switches for testing, read at hmg_ctx_create: HMG_FUSED_FFT=0 (rocFFT for everything), HMG_PRUNED_FFT=0,
- * HMG_CHIRP=0, HMG_PRUNED_LP_MIN, HMG_FUSED_MAX_M, HMG_FUSED_PREFER_M.                                              */
+ * HMG_CHIRP=0, HMG_BAND_FFT=0, HMG_PRUNED_LP_MIN, HMG_FUSED_MAX_M, HMG_FUSED_PREFER_M.                             */
 int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_step,
                     const double* d_xs, const double* d_kts,
                     const double* d_amp, const double* d_xc, const double* d_alpha,

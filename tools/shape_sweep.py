@@ -87,6 +87,10 @@ def main():
              ten, pressure=(5000, 5))
     run_case("HOD with central_profile_name='electron' (generic mass-integral forms), six spectra", zs, ms, ks,
              (5000, 20), six, central=True)
+    run_case("tSZ notebook's pressure profile (nxs=30000, xmax=2) + 10 spectra: narrow-band route", zs, ms, ks, (5000, 20),
+             ten, pressure=(30000, 2))
+    run_case("the same through rocFFT (HMG_BAND_FFT=0)", zs, ms, ks, (5000, 20), ten, pressure=(30000, 2),
+             env={"HMG_BAND_FFT": "0"}, reps=5)
     print("# README grid 20 x 200 x 1001 (BASELINE configs 1/2), six spectra")
     zs = np.linspace(0., 3., 20); ms = np.geomspace(2e10, 1e17, 200); ks = np.geomspace(1e-4, 100, 1001)
     run_case("README grid: nxs=5000 xmax=20", zs, ms, ks, (5000, 20), six)
