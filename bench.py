@@ -355,6 +355,32 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
             for k_ in env:
                 os.environ.pop(k_, None)
     out["max_abs_du_between_routes"] = float(np.max(np.abs(tens["pruned"] - tens["rocfft"])))
+    # the third caller with a long grid: the tSZ notebook's pressure profile, whose support does not prune
+    tsz = {"profile": "add_battaglia_pres_profile('y', family='pres', xmax=2, nxs=30000)  (examples/tSZ example.ipynb)"}
+    pk = {}
+    for route, env in (("narrow_band", {}), ("rocfft", {"HMG_BAND_FFT": "0"})):
+        for k_, v_ in env.items():
+            os.environ[k_] = v_
+        try:
+            c2 = nat.Context(ctx.device)
+            h2 = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic", ctx=c2)
+            t_ = []
+            for i in range(2 + (reps if route != "rocfft" else 3)):
+                c2.call("hmg_bracket_next", nat.KERNEL_PROFILE_FFT, 44, 45)
+                h2.add_battaglia_pres_profile("y", family="pres", xmax=2, nxs=30000, ignore_existing=True)
+                c2.sync()
+                if i >= 2:
+                    t_.append(c2.elapsed_ms(44, 45))
+            tsz[route] = {"profile_stage_ms": float(np.median(t_))}
+            pk[route] = h2.pk_profiles["y"][::4, ::16]
+            del h2
+            c2.close()
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+    scale = np.max(np.abs(pk["rocfft"]), axis=-1, keepdims=True)
+    tsz["max_dp_over_rowmax_between_routes"] = float(np.max(np.abs(pk["narrow_band"] - pk["rocfft"]) / scale))
+    out["tsz_pressure"] = tsz
     out["note"] = ("pass_wall_ms_eager: one pass = mass function + NFW + this profile + HOD + the batched spectra, eager "
                    "launches, host-synchronised after every pass (the headline ms_per_step is a HIP-graph replay); "
                    "tolerance on u is 1e-12 absolute (tests/test_gpu_longgrid.py holds both routes to the reference's "
