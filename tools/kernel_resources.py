@@ -19,6 +19,8 @@ KERNELS = [   # (label, regex on the mangled name)
     ("power_batch_kernel<2,3,1,true,593>  (thin slab)", r"power_batch_kernelILi2ELi3ELi1ELb1ELj593E"),
     ("profile_pruned_kernel<512,1000>  (nxs = 30000)", r"profile_pruned_kernelILi512ELi1000E"),
     ("profile_pruned_kernel<512,1250>  (nxs = 40000)", r"profile_pruned_kernelILi512ELi1250E"),
+    ("profile_band_kernel<512,1000,1>  (tSZ: nxs = 30000, xmax = 2, <= 255 modes)", r"profile_band_kernelILi512ELi1000ELi1E"),
+    ("profile_band_kernel<512,1000,2>  (the same, up to 499 modes)", r"profile_band_kernelILi512ELi1000ELi2E"),
     ("stand-alone: profile_fused_kernel<512,2,3,2500>", r"profile_fused_kernelILi512ELi2ELi3ELi2500E"),
     ("stand-alone: nfw_kernel", r"10nfw_kernelE"),
 ]
