@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_lds; mkdir -p $OUT
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $OUT/g -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-graph > $OUT/g.log 2>&1 || { tail -5 $OUT/g.log; exit 1; }
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $OUT/g -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-limber --no-readme --no-long-grid --no-graph $PMC_BENCH_FLAGS > $OUT/g.log 2>&1 || { tail -5 $OUT/g.log; exit 1; }
 python3 - $OUT "${1:-}" <<'PY'
 import csv, re, sys
 from collections import defaultdict
