@@ -85,9 +85,11 @@ struct FusedPlan {
     int maxb = 0, maxp = 0;
 };
 
-struct PrunedPlan {                       // tables of the pruned long-grid route, per nxs
-    hmg::cplx* twB = nullptr;             // exp(-2 pi i t / M), t < M = nxs/2
-    hmg::UnpackTw* twN = nullptr;         // unpack constants for j <= M/2
+struct PrunedPlan {                       // tables of the long-grid routes, per (nxs, LP); LP = 0: the mode-ordered pair
+    hmg::cplx* twB = nullptr;             // LP == 0: exp(-2 pi i t / M), t < M = nxs/2 (narrow-band route)
+    hmg::UnpackTw* twN = nullptr;         // LP == 0: unpack constants for j <= M/2 by mode (chirp and narrow-band routes)
+    hmg::cplx* twR = nullptr;             // LP > 0: the residues' twiddles on the samples, by residue (ldsfft.hpp)
+    hmg::UnpackTw* twNr = nullptr;        // LP > 0: unpack constants by residue
 };
 struct ChirpPlan {                        // tables of the chirp route (ldsfft.hpp: ChirpTables), per (nxs, LP, p0)
     hmg::cplx *chP = nullptr, *chJ = nullptr, *Bw = nullptr;
@@ -122,7 +124,8 @@ struct hmg_ctx {
     int use_chirp = 1;                             // HMG_CHIRP=0: every row of a long grid takes the decomposition
     int use_band_fft = 1;                          // HMG_BAND_FFT=0: supports that do not prune go to rocFFT
     std::map<std::tuple<int, int, int>, ChirpPlan> chirp;   // (nxs, LP, p0) -> tables
-    std::map<int, PrunedPlan> pruned;              // nxs -> tables of the pruned long-grid route
+    std::map<std::pair<int, int>, PrunedPlan> pruned;   // (nxs, LP) -> tables of the long-grid routes
+    std::map<int, hmg::cplx*> pass_tw;             // L -> per-pass twiddle table of the length-L plan (ldsfft.hpp)
     std::map<SupportKey, std::pair<int, int>> support;   // last measured bounds of a launch's rows: (support in packed samples, needed modes)
     int* d_fault = nullptr;                        // device word a kernel raises when it cannot do what it was launched for
     int* h_fault = nullptr;                        // its pinned host twin
@@ -2800,7 +2803,10 @@ int hmg_ctx_destroy(hmg_ctx* c) {
     for (auto& kv : c->pruned) {
         if (kv.second.twB) (void)hipFree(kv.second.twB);
         if (kv.second.twN) (void)hipFree(kv.second.twN);
+        if (kv.second.twR) (void)hipFree(kv.second.twR);
+        if (kv.second.twNr) (void)hipFree(kv.second.twNr);
     }
+    for (auto& kv : c->pass_tw) (void)hipFree(kv.second);
     if (c->d_fault) (void)hipFree(c->d_fault);
     if (c->h_fault) (void)hipHostFree(c->h_fault);
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
@@ -3500,23 +3506,49 @@ static int launch_fused_group(hmg_ctx* c, const FusedArgs& A, int rows, const Ch
 // and covers the support bound of its rows.
 static const int PRUNED_LP[] = {1000, 1024, 1250, 1500, 2000, 2048, 2500};
 
-static int get_pruned_plan(hmg_ctx* c, int nxs, PrunedPlan** out) {
-    auto it = c->pruned.find(nxs);
+template <class T>
+static int upload_table(const std::vector<T>& h, T** d) {
+    HIP_TRY(hipMalloc((void**)d, h.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// LP == 0: the tables by mode (chirp and narrow-band routes); LP > 0: the decomposition's tables by residue
+static int get_pruned_plan(hmg_ctx* c, int nxs, int LP, PrunedPlan** out) {
+    const auto key = std::make_pair(nxs, LP);
+    auto it = c->pruned.find(key);
     if (it != c->pruned.end()) { *out = &it->second; return 0; }
+    REQUIRE(!c->capturing, "long-grid tables cannot be built inside a captured step: run the step once eagerly first");
     const int M = nxs / 2;
     PrunedPlan P;
-    std::vector<cplx> twB(M);
-    std::vector<UnpackTw> twN(M / 2 + 1);
-    const long double twopi = 6.283185307179586476925286766559L;
-    for (int t = 0; t < M; ++t) twB[t] = cplx{(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
-    for (int j = 0; j <= M / 2; ++j)
-        twN[j] = UnpackTw{(double)cosl(twopi * j / nxs), (double)sinl(twopi * j / nxs), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
-    HIP_TRY(hipMalloc((void**)&P.twB, twB.size() * sizeof(cplx)));
-    HIP_TRY(hipMalloc((void**)&P.twN, twN.size() * sizeof(UnpackTw)));
-    HIP_TRY(hipMemcpy(P.twB, twB.data(), twB.size() * sizeof(cplx), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(P.twN, twN.data(), twN.size() * sizeof(UnpackTw), hipMemcpyHostToDevice));
-    auto res = c->pruned.emplace(nxs, P);
+    if (LP == 0) {
+        std::vector<cplx> twB(M);
+        std::vector<UnpackTw> twN(M / 2 + 1);
+        const long double twopi = 6.283185307179586476925286766559L;
+        for (int t = 0; t < M; ++t) twB[t] = cplx{(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
+        for (int j = 0; j <= M / 2; ++j)
+            twN[j] = UnpackTw{(double)cosl(twopi * j / nxs), (double)sinl(twopi * j / nxs), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
+        if (upload_table(twB, &P.twB) || upload_table(twN, &P.twN)) return 1;
+    } else {
+        if (upload_table(residue_tw_table(M, LP), &P.twR) || upload_table(residue_unpack_table(M, LP), &P.twNr)) return 1;
+    }
+    auto res = c->pruned.emplace(key, P);
     *out = &res.first->second;
+    return 0;
+}
+
+// Per-pass twiddle table of the length-L plan the long-grid kernels are compiled for (independent of the lengths the
+// one-row kernel takes: HMG_FUSED_MAX_M does not reach here).
+static int get_pass_table(hmg_ctx* c, int L, const cplx** out) {
+    auto it = c->pass_tw.find(L);
+    if (it != c->pass_tw.end()) { *out = it->second; return 0; }
+    REQUIRE(!c->capturing, "long-grid tables cannot be built inside a captured step: run the step once eagerly first");
+    FftPlanDev plan;
+    REQUIRE(fft_make_plan(L, &plan), "no radix-2/3/4/5 plan for a compiled sub-transform length");
+    cplx* d = nullptr;
+    if (upload_table(pass_tw_table(plan), &d)) return 1;
+    c->pass_tw[L] = d;
+    *out = d;
     return 0;
 }
 
@@ -3595,15 +3627,14 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
             if (M % lb == 0 && band_lb_compiled(lb) && 2 * jnmax + 2 <= lb) { LB = lb; break; }
         if (!LB) return 0;
         PrunedPlan* PP = nullptr;
-        FusedPlan* FL = nullptr;
-        if (get_pruned_plan(c, nxs, &PP)) return 1;
-        if (get_fused_plan(c, 2 * LB, &FL)) return 1;
-        REQUIRE(FL != nullptr, "no twiddle table for the band transform length");
+        const cplx* twL = nullptr;
+        if (get_pruned_plan(c, nxs, 0, &PP)) return 1;
+        if (get_pass_table(c, LB, &twL)) return 1;
         PrunedArgs G{};
         G.F = A0;
         G.F.twN = PP->twN;
         if (ensure_scratch(c, 0, (size_t)3 * nxs * 8)) return 1;       // x, ln x, trapezoid weights in the kernel's walk order
-        G.M = M; G.R = M / LB; G.twB = PP->twB; G.twL = FL->twM; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
+        G.M = M; G.R = M / LB; G.twB = PP->twB; G.twL = twL; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
         int stop = -1;
         if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
         HIP_TRY((hipError_t)launch_band(c->stream, LB, G, rows, jnmax));
@@ -3611,11 +3642,11 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
         *taken = 1;
         return bracket_close(c, stop);
     }
-    PrunedPlan* PP = nullptr;
-    FusedPlan* FL = nullptr;
-    if (get_pruned_plan(c, nxs, &PP)) return 1;
-    if (get_fused_plan(c, 2 * LP, &FL)) return 1;
-    REQUIRE(FL != nullptr, "no twiddle table for the sub-transform length");
+    PrunedPlan *PP = nullptr, *PR = nullptr;
+    const cplx* twL = nullptr;
+    if (get_pruned_plan(c, nxs, 0, &PP)) return 1;
+    if (get_pruned_plan(c, nxs, LP, &PR)) return 1;
+    if (get_pass_table(c, LP, &twL)) return 1;
     // scratch line of M doubles per row, at most 8 GiB per launch
     size_t rpl = ((size_t)8 << 30) / ((size_t)M * 8);
     if (rpl < 1) rpl = 1;
@@ -3624,7 +3655,9 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
     PrunedArgs G;
     G.F = A0;
     G.F.twN = PP->twN;
-    G.M = M; G.R = M / LP; G.twB = PP->twB; G.twL = FL->twM; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
+    G.M = M; G.R = M / LP; G.twB = PP->twB; G.twL = twL; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
+    G.twR = PR->twR; G.twNr = PR->twNr; G.rmagic = (unsigned)(4294967296ull / (unsigned)G.R) + 1u;
+    G.lpt_nz = 0;
     G.chP = G.chJ = G.Bw = G.twC = nullptr;
     G.Jw = 0; G.p0 = 0;
     if (c->use_chirp && (LP == 1000 || LP == 1250) && p0max >= 1) {
@@ -3632,17 +3665,14 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
         int p0 = (p0max + 15) / 16 * 16;
         if (p0 > LP) p0 = LP;
         ChirpPlan* CP = nullptr;
-        FusedPlan* FC = nullptr;
+        const cplx* twC = nullptr;
         if (get_chirp_plan(c, nxs, LP, p0, &CP)) return 1;
-        if (get_fused_plan(c, 4 * LP, &FC)) return 1;
-        REQUIRE(FC != nullptr, "no twiddle table for the chirp transform length");
-        G.chP = CP->chP; G.chJ = CP->chJ; G.Bw = CP->Bw; G.twC = FC->twM; G.Jw = CP->Jw; G.p0 = p0;
+        if (get_pass_table(c, 2 * LP, &twC)) return 1;
+        G.chP = CP->chP; G.chJ = CP->chJ; G.Bw = CP->Bw; G.twC = twC; G.Jw = CP->Jw; G.p0 = p0;
     }
-    int rc = 1, stop = -1;
+    int stop = -1;
     if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
     HIP_TRY((hipError_t)launch_pruned(c->stream, LP, G, rows, rpl));
-    rc = 0;
-    if (rc) return 1;
     c->fault_armed = true;
     *taken = 1;
     return bracket_close(c, stop);

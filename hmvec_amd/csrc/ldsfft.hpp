@@ -98,6 +98,22 @@ constexpr bool fft_plan_fill(int M, FftPlanDev& p) {
             p.radix[j] = p.radix[j - 1];
             p.radix[j - 1] = tmp;
         }
+    // A power-of-two pass right behind a power-of-two first pass stores 16-byte elements at q*(Ns R) + k + t*Ns with
+    // Ns R = 8 or 16: the eight lanes of a ds_write_b128 group then fall on two or four 16-byte slots modulo 128 B (a
+    // 4-way bank conflict for M = 1000: 2,4,...).  With a radix-5 pass in that place the blocks are 10 or 20 elements
+    // apart and the eight lanes cover all eight slots.  The order of the passes behind the first is free (HMG_PLAN_ORDER=0
+    // in a build keeps the plain ascending order: A/B timing).
+#ifndef HMG_PLAN_ORDER
+#define HMG_PLAN_ORDER 1
+#endif
+    if (HMG_PLAN_ORDER && p.npass >= 3 && (p.radix[0] == 2 || p.radix[0] == 4) && (p.radix[1] == 2 || p.radix[1] == 4)) {
+        for (int i = 2; i < p.npass; ++i)
+            if (p.radix[i] == 5) {
+                for (int j = i; j > 1; --j) p.radix[j] = p.radix[j - 1];
+                p.radix[1] = 5;
+                break;
+            }
+    }
     int Ns = 1;
     for (int i = 0; i < p.npass; ++i) {
         p.ns[i] = Ns;
@@ -113,6 +129,19 @@ constexpr FftPlanDev fft_plan_c(int M) {
     fft_plan_fill(M, p);
     return p;
 }
+
+// Per-pass twiddle tables.  Pass ps of a length-M plan multiplies by W_M^(k twstep), k = j mod Ns < Ns.  Read from the
+// one table exp(-2 pi i t / M) that is a gather at a stride of twstep 16-byte elements: for the passes in the middle of a
+// plan (M = 1000: Ns = 40, twstep = 5) every lane of a wavefront touches a cache line of its own and the load takes the
+// CU's texture-address unit 64 cycles instead of 16 (measured on MI355X in round 5: the uncoalesced table reads of the
+// long-grid kernel, not its arithmetic, were its largest single cost).  Laid out per pass - [sum of the earlier Ns + k] -
+// consecutive butterflies read consecutive elements; the whole set has sum(Ns) < M/2 entries.
+constexpr int pass_tw_offset(const FftPlanDev& p, int ps) {
+    int o = 0;
+    for (int i = 0; i < ps; ++i) o += p.ns[i];
+    return o;
+}
+constexpr int pass_tw_total(const FftPlanDev& p) { return pass_tw_offset(p, p.npass); }
 
 // In-place forward DFTs of size R (sign -).
 template <int R>
@@ -178,6 +207,17 @@ HMG_HD void dft5_lead3(cplx* v) {
     v[3] = csub(m2, n2);
 }
 
+inline std::vector<cplx> pass_tw_table(const FftPlanDev& p) {
+    std::vector<cplx> t((size_t)pass_tw_total(p));
+    const long double twopi = 6.283185307179586476925286766559L;
+    for (int ps = 0; ps < p.npass; ++ps)
+        for (int k = 0; k < p.ns[ps]; ++k) {
+            const long double a = twopi * (long double)((long long)k * p.twstep[ps]) / (long double)p.M;
+            t[(size_t)pass_tw_offset(p, ps) + k] = cplx{(double)cosl(a), (double)-sinl(a)};
+        }
+    return t;
+}
+
 // One Stockham pass of radix R on butterfly j (0 <= j < M/R), sub-transform size Ns so far:
 //   load:  v[t] = buf[j + t*M/R] * W_M^(t * k * M/(Ns*R)),  k = j mod Ns  (no integer division: fast_div)
 //   store: buf[(j div Ns)*Ns*R + k + t*Ns] = DFT_R(v)[t]
@@ -199,7 +239,11 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twste
     // cycles on one of four SIMDs).
     // k == 0 is not special-cased: its twiddle is twM[0] = 1 exactly, and a branch would make
     // every wavefront that holds such a lane walk both paths.
+#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 1)      // timing experiment: no twiddle fetch in the passes
+    const cplx w1 = cplx{0.6 + 1e-9 * k, 0.8};
+#else
     const cplx w1 = twM[mul_idx<SMALL>(k, twstep)];
+#endif
     cplx w = w1;
 #pragma unroll
     for (int t = 1; t < NIN; ++t) {
@@ -278,19 +322,21 @@ struct SubPass {
     static constexpr bool SMALL = nb <= 1024 && Ns <= 1024;
     static constexpr unsigned mg = SMALL ? small_magic((unsigned)Ns) : P.magic[PS];
     static constexpr bool last = PS == P.npass - 1;
+    static constexpr int twoff = pass_tw_offset(P, PS);      // this pass's slice of the per-pass twiddle table
 };
+// twP: the per-pass twiddle table of the length-LP plan (pass_tw_table)
 template <int LP, int PS>
-HMG_HD void sub_pass_load(const cplx* buf, const cplx* twL, int jj, cplx* v) {
+HMG_HD void sub_pass_load(const cplx* buf, const cplx* twP, int jj, cplx* v) {
     using S = SubPass<LP, PS>;
     const int b = jj >= S::nb ? 1 : 0, j = jj - b * S::nb;
-    pass_load<S::R, S::SMALL>(buf + b * LP, twL, LP, S::Ns, S::tws, S::mg, j, v);
+    pass_load<S::R, S::SMALL>(buf + b * LP, twP + S::twoff, LP, S::Ns, 1, S::mg, j, v);
 }
 // the same with the twiddle held by the caller: sub_pass_twiddle once, sub_pass_load_w per transform
 template <int LP, int PS>
-HMG_HD cplx sub_pass_twiddle(const cplx* twL, int jj) {
+HMG_HD cplx sub_pass_twiddle(const cplx* twP, int jj) {
     using S = SubPass<LP, PS>;
     const int j = jj >= S::nb ? jj - S::nb : jj;
-    return twL[pass_twiddle_index<S::R, S::SMALL>(S::Ns, S::tws, S::mg, j)];
+    return twP[S::twoff + pass_twiddle_index<S::R, S::SMALL>(S::Ns, 1, S::mg, j)];
 }
 template <int LP, int PS>
 HMG_HD void sub_pass_load_w(const cplx* buf, int jj, cplx w1, cplx* v) {
@@ -315,14 +361,40 @@ HMG_HD bool sub_pass_active(int jj, int nbuf, int keep) {
     return j <= keep || j >= S::nb - keep;
 }
 
+// Tables and the scratch line of the decomposition are laid out BY RESIDUE, so that the threads of a wavefront - which
+// walk consecutive quotients q of one residue s - touch consecutive elements (by mode j = s + R q they would be R
+// elements apart: one cache line per lane):
+//   twR[s LP + p]  = W_M^(s p)            the residue's twiddles on the samples           (residue_tw_table)
+//   twNr[s QS + q] = unpack constants of mode j = s + R q <= M/2, QS = LP/2 + 1          (residue_unpack_table)
+//   u[s LP + q]    = u_j, j = s + R q, 1 <= j < M                                         (pruned_u_index)
+HMG_HD int pruned_qs(int LP) { return LP / 2 + 1; }
+HMG_HD int pruned_u_index(int R, int LP, unsigned rmagic, int j) {
+    const int q = (int)fast_div((unsigned)j, rmagic);      // rmagic = 2^32 / R + 1 (exact far beyond any M)
+    return (j - q * R) * LP + q;
+}
+inline std::vector<cplx> residue_tw_table(int M, int LP) {
+    const int R = M / LP;
+    std::vector<cplx> t((size_t)R * LP);
+    const long double twopi = 6.283185307179586476925286766559L;
+    for (int s = 0; s < R; ++s)
+        for (int p = 0; p < LP; ++p) {
+            const long double a = twopi * (long double)(((long long)s * p) % M) / (long double)M;
+            t[(size_t)s * LP + p] = cplx{(double)cosl(a), (double)-sinl(a)};
+        }
+    return t;
+}
 // Unpack step of one residue of a transformed pair: thread `tid` of `nthreads` walks the quotients q = tid,
 // tid + nthreads, ... of residue s (its transform in buffer ob, the partner residue's in buffer pb), forms
 // Im F_j and Im F_{M-j} of every needed pair (j <= jn, or the mirror M - j <= jn) and stores
-// u_j = Im F_j * sc / j at u[j-1].  Modes above M/2 are reached as mirrors from the partner residue.
-HMG_HD void pruned_unpack(const cplx* buf, int LP, int R, int M, int s, int ob, int pb, int jn, const UnpackTw* twN,
+// u_j = Im F_j * sc / j at its place in the residue-major line.  Modes above M/2 are reached as mirrors from the
+// partner residue: M - j sits in residue (R - s) mod R at quotient pr.qp.
+HMG_HD void pruned_unpack(const cplx* buf, int LP, int R, int M, int s, int ob, int pb, int jn, const UnpackTw* twNr,
                           double sc, double* u, int tid, int nthreads) {
     const int half = M / 2;
     const bool hi_any = jn >= M - half;             // does any mirror M - j with j <= M/2 lie within jn at all
+    const UnpackTw* tws = twNr + (size_t)s * pruned_qs(LP);
+    double* us = u + (size_t)s * LP;
+    double* um = u + (size_t)(s == 0 ? 0 : R - s) * LP;
     for (int q = tid + (s == 0 ? 1 : 0);; q += nthreads) {
         const PrunedPair pr = pruned_pair(R, LP, s, q);
         if (pr.j > half) break;
@@ -332,12 +404,24 @@ HMG_HD void pruned_unpack(const cplx* buf, int LP, int R, int M, int s, int ob, 
             continue;
         }
         const cplx zj = buf[ob * LP + q], zmj = buf[pb * LP + pr.qp];
-        const UnpackTw w = twN[pr.j];
+        const UnpackTw w = tws[q];
         double fa, fb;
         unpack_imag_pair(zj, zmj, w.co, w.si, fa, fb);
-        u[pr.j - 1] = fa * sc * w.rj;
-        if (hi && M - pr.j >= 1) u[M - pr.j - 1] = fb * sc * w.rmj;
+        us[q] = fa * sc * w.rj;
+        if (hi && M - pr.j >= 1) um[pr.qp] = fb * sc * w.rmj;
     }
+}
+inline std::vector<UnpackTw> residue_unpack_table(int M, int LP) {
+    const int R = M / LP, QS = pruned_qs(LP), n = 2 * M;
+    std::vector<UnpackTw> t((size_t)R * QS, UnpackTw{1.0, 0.0, 0.0, 0.0});
+    const long double twopi = 6.283185307179586476925286766559L;
+    for (int s = 0; s < R; ++s)
+        for (int q = 0; q < QS; ++q) {
+            const int j = s + R * q;
+            if (j > M / 2) break;
+            t[(size_t)s * QS + q] = UnpackTw{(double)cosl(twopi * j / n), (double)sinl(twopi * j / n), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
+        }
+    return t;
 }
 // Which residues a group g = 0 .. R/2 transforms: g and R - g (one buffer for the self-paired g = 0 and 2g = R),
 // and whether a row that needs the modes j <= jn needs the group at all.

@@ -22,9 +22,6 @@ namespace hmg {
 // (Measured and dropped, MI355X: a thread works on the same butterflies in every group of residues, so its twiddle
 // per pass can be fetched once per row and held in registers - 16 more VGPRs at LP = 1000 spill inside the group loop
 // under the 64- and the 80-register caps alike: 1.16 -> 2.38 / 2.04 ms.)
-#ifndef HMG_PRUNED_TWLDS
-#define HMG_PRUNED_TWLDS 0
-#endif
 template <int NT, int LP, int PS, int NBUF = 2>
 __device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* twL, int nbuf, int keep) {
     if constexpr (PS < SubPass<LP, 0>::P.npass) {
@@ -53,6 +50,18 @@ template <int LP> constexpr bool chirp_ok() {
     else return false;
 }
 
+#ifndef HMG_PRUNED_ULDS
+#define HMG_PRUNED_ULDS 1
+#endif
+#ifndef HMG_PRUNED_LPT
+#define HMG_PRUNED_LPT 0
+#endif
+// LDS of a row workgroup: [0, 2 LP) cplx transform buffers | 32 doubles of scalars | the modes of a chirp row
+// (rows with more modes than fit take the decomposition)
+template <int LP> constexpr int pruned_uls_doubles() { return (HMG_PRUNED_ULDS && chirp_ok<LP>()) ? (LP / 2 + LP / 8 + 8) / 2 * 2 : 0; }
+template <int LP> constexpr size_t pruned_lds_bytes() {
+    return (size_t)2 * LP * 16 + (32 + pruned_uls_doubles<LP>()) * sizeof(double);
+}
 template <int NT, int LP>
 __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row, double* smem) {
     const FusedArgs& A = G.F;
@@ -64,14 +73,10 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     double* red = smem + 4 * (size_t)LP;
     int* s_cnt = reinterpret_cast<int*>(red + 17);
     int* s_jn = reinterpret_cast<int*>(red + 18);
-#if HMG_PRUNED_TWLDS
-    // the twiddle table of the sub-transforms in LDS behind the scalars: the passes of the group loop then make no
-    // global access at all (one ds_read_b128 per butterfly instead of an L2 round trip per pass)
-    cplx* twl = reinterpret_cast<cplx*>(red + 32);
-    for (int t = threadIdx.x; t < LP; t += NT) twl[t] = G.twL[t];
-#else
+    // behind the scalars: the modes u_j of a row that took the chirp route (jn <= Jw: a few hundred) - they never
+    // leave the CU; only the rows of the decomposition use the scratch line in HBM/L2
+    double* uls = red + 32;
     const cplx* __restrict__ twl = G.twL;
-#endif
     using S0 = SubPass<LP, 0>;
     constexpr int R0 = S0::R, nb0 = S0::nb, MAXB0 = (nb0 + NT - 1) / NT;
     static_assert(S0::Ns == 1, "first pass");
@@ -140,8 +145,13 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                 const int j = 2 * (jb + t * nb0);
                 const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
                 double r0 = 0.0, r1 = 0.0;
+#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 64)     // timing experiment: no transcendentals in the integrand
+                if (!(fabs(xv.x) > cm)) r0 = Aamp * xv.x + AL;
+                if (!(fabs(xv.y) > cm)) r1 = Aamp * xv.y + EX;
+#else
                 if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
                 if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+#endif
                 zp[b][t] = cplx{xv.x * r0, xv.y * r1};
                 if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
                     const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
@@ -165,14 +175,15 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
     // ---- phase B + C: per group of residues {g, R - g}: first pass from registers, the other passes in LDS,
     // unpack into the scratch line
-    double* __restrict__ u = G.u + (size_t)(row - G.row0) * M;
+    double* u = G.u + (size_t)(row - G.row0) * M;
     constexpr int nb_last = SubPass<LP, S0::P.npass - 1>::nb;
     const int keep = pruned_keep(R, M, nb_last, jn);
     bool chirped = false;
     if constexpr (chirp_ok<LP>()) {
         // ---- rows that need few modes: the chirp route - two transforms of length 2 LP instead of R of length LP
         // (the window was built for supports up to p0 packed samples: a row beyond it takes the decomposition)
-        if (G.Bw != nullptr && jn <= G.Jw && A.xs[2 * G.p0 < nxs ? 2 * G.p0 : nxs - 1] > cm) {
+        if (G.Bw != nullptr && jn <= G.Jw && (!HMG_PRUNED_ULDS || jn <= pruned_uls_doubles<LP>()) &&
+            A.xs[2 * G.p0 < nxs ? 2 * G.p0 : nxs - 1] > cm) {
             chirped = true;
             constexpr int LC = 2 * LP;
             using C0 = SubPass<LC, 0>;
@@ -214,12 +225,16 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
             }
             pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, (2 * jn + 2 < nb_last_c) ? jn : -1);
             const double sc = red[24];
+            double* __restrict__ ud = HMG_PRUNED_ULDS ? uls : u;
             for (int j = 1 + (int)threadIdx.x; j <= jn; j += NT) {
                 const UnpackTw w = A.twN[j];
-                u[j - 1] = chirp_unpack(buf, LC, j, G.chJ[j], w) * sc * w.rj;
+                ud[j - 1] = chirp_unpack(buf, LC, j, G.chJ[j], w) * sc * w.rj;
             }
         }
     }
+#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 32)     // timing experiment: no group loop at all
+    chirped = true;
+#endif
     for (int g = 0; g <= R / 2 && !chirped; ++g) {
         if (!pruned_group_needed(R, M, g, jn)) break;          // (groups are needed in ascending order of g)
         const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
@@ -232,8 +247,9 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                     if (h < nbuf) {
                         const int sres = h ? s1 : g;
                         cplx v[R0];
+                        const cplx* __restrict__ twr = G.twR + (size_t)sres * LP;      // W_M^(sres p): consecutive p
 #pragma unroll
-                        for (int t = 0; t < R0; ++t) v[t] = cmul(zp[b][t], G.twB[sres * (jb + t * nb0)]);
+                        for (int t = 0; t < R0; ++t) v[t] = cmul(zp[b][t], twr[jb + t * nb0]);
                         dft_small<R0>(v);
 #pragma unroll
                         for (int t = 0; t < R0; ++t) buf[h * LP + jb * R0 + t] = v[t];      // Ns = 1: q = j, k = 0
@@ -242,19 +258,29 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
             }
         }
         __syncthreads();                                       // (also publishes red[24] before the first unpack)
+#if !(defined(HMG_LG_ABL) && (HMG_LG_ABL & 4))   // timing experiment: without the passes in LDS
         pruned_passes<NT, LP, 1>(buf, twl, nbuf, keep);
+#endif
         const double sc = red[24];
-        pruned_unpack(buf, LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
-        if (nbuf == 2) pruned_unpack(buf, LP, R, M, s1, 1, 0, jn, A.twN, sc, u, (int)threadIdx.x, NT);
+#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 8)      // timing experiment: without the unpack step
+        if (g == 0 && threadIdx.x < 64) u[threadIdx.x] = buf[threadIdx.x].x * sc;
+        __syncthreads();
+        continue;
+#endif
+        pruned_unpack(buf, LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, G.twNr, sc, u, (int)threadIdx.x, NT);
+        if (nbuf == 2) pruned_unpack(buf, LP, R, M, s1, 1, 0, jn, G.twNr, sc, u, (int)threadIdx.x, NT);
         __syncthreads();                                       // the next group overwrites the buffers
     }
-    if (threadIdx.x == 0) u[M - 1] = 0.0;                      // Nyquist mode: Im F_M == 0
-    __threadfence_block();
-    __syncthreads();                                           // u (global) is read by other threads below
+    // A chirp row's modes sit by mode number - u_j at [j-1] - in LDS (or, without HMG_PRUNED_ULDS, in the scratch line);
+    // the decomposition's in the scratch line by residue.  Mode M (Nyquist, Im F_M == 0) has no slot there: the
+    // interpolation substitutes the zero.
+    if (HMG_PRUNED_ULDS && chirped) u = uls;                   // (jn <= Jw < M - 4: mode M is never read)
+    else __threadfence_block();
+    __syncthreads();                                           // u is read by other threads below
     // ---- phase D: as profile_fused_row, the modes read from the scratch line
     const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
     const double pf = A.post ? A.post[row] : 1.0;
-    const double u1 = u[0];
+    const double u1 = chirped ? u[0] : u[R > 1 ? LP : 1];        // mode 1: residue 1, quotient 0
     const int nleft = A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0;
     if (nleft > 0) {
         typedef double v2d __attribute__((ext_vector_type(2)));
@@ -273,8 +299,21 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         int j = (int)(k * inv_dk);
         j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
         const double fr = fma(k, inv_dk, -(double)j);
-        const double y0 = u[j - 1], y1 = u[j];
+#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 16)     // timing experiment: interpolation without the mode loads
+        return fr + (double)j;
+#else
+        double y0, y1;
+        if (chirped) {
+            y0 = u[j - 1]; y1 = u[j];
+        } else {                                   // modes j and j + 1 of the residue-major line
+            const int q = (int)fast_div((unsigned)j, G.rmagic), sr = j - q * R;
+            const int i0 = sr * LP + q;
+            const int i1 = sr + 1 < R ? i0 + LP : q + 1;
+            y0 = u[i0];
+            y1 = j + 1 < M ? u[i1] : 0.0;
+        }
         return fma(y1 - y0, fr, y0);
+#endif
     };
     if (A.nconst) {
         for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
@@ -298,16 +337,27 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
 #ifndef HMG_PRUNED_OCC
 #define HMG_PRUNED_OCC 0
 #endif
-// waves per SIMD the LDS footprint (two buffers of LP complex numbers [+ the twiddle table]) allows a 512-thread
-// workgroup: 2 per workgroup
-template <int LP> constexpr int pruned_occ() {
-    constexpr int wgs = (160 * 1024) / ((2 + HMG_PRUNED_TWLDS) * LP * 16 + 256);
-    return HMG_PRUNED_OCC ? HMG_PRUNED_OCC : (wgs >= 4 ? 8 : 2 * wgs);
+// waves per SIMD the LDS footprint (two buffers of LP complex numbers, the scalars, the chirp rows' modes) allows:
+// NT/64 per workgroup
+template <int NT, int LP> constexpr int pruned_occ() {
+    constexpr int wgs = (160 * 1024) / (int)pruned_lds_bytes<LP>();
+    constexpr int w = wgs * (NT / 64) / 4;
+    return HMG_PRUNED_OCC ? HMG_PRUNED_OCC : (w >= 8 ? 8 : (w < 1 ? 1 : w));
 }
 template <int NT, int LP>
-__global__ __launch_bounds__(NT, pruned_occ<LP>()) void profile_pruned_kernel(PrunedArgs G) {
+__global__ __launch_bounds__(NT, (pruned_occ<NT, LP>())) void profile_pruned_kernel(PrunedArgs G) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    profile_pruned_row<NT, LP>(G, G.row0 + blockIdx.x, smem);
+    // Heavy rows first: the cost of a row grows with the modes it needs, jn ~ r_s (1+z), i.e. with the mass - and the
+    // rows of a launch are laid out [z][m], m ascending.  Walking the masses downwards across all redshifts
+    // (block b -> z = b mod nz, m = nm - 1 - b / nz) hands the rows that take the decomposition out first and leaves
+    // the cheap chirp rows for the end of the launch, where they fill the tail (a launch covering whole redshifts only).
+    int b = blockIdx.x;
+    if (HMG_PRUNED_LPT && G.row0 == 0 && G.lpt_nz > 0) {
+        const int nz = G.lpt_nz, nm = G.F.nm;
+        const int q = b / nz;
+        b = (b - q * nz) * nm + (nm - 1 - q);
+    }
+    profile_pruned_row<NT, LP>(G, G.row0 + b, smem);
 }
 
 // ---- Rows whose support does not prune but which need few modes: the narrow-band route (ldsfft.hpp).  The tSZ notebook
@@ -352,7 +402,7 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
     // the needed modes allows: 24 registers fewer)
     constexpr int nb_last = SubPass<LB, S0::P.npass - 1>::nb;
     static_assert(S0::Ns == 1, "first pass");
-    const int M = G.M, D = G.R, nxs = 2 * M;
+    const int M = G.M, D = G.R;
     const double Aamp = A.amp ? A.amp[row] : A.amp_c;
     const double XC = A.xc ? A.xc[row] : A.xc_c;
     const double AL = A.alpha ? A.alpha[row] : A.alpha_c;
@@ -483,7 +533,7 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
     __syncthreads();
     // ---- interpolation: as profile_fused_row, the modes read from LDS (targets beyond mode jn - 2 do not exist:
     // jn = floor(max(ks)/k_lo) + 3)
-    const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
+    const double k_hi = red[21], inv_dk = red[22];
     const double pf = A.post ? A.post[row] : 1.0;
     const double u1 = us[0];
     const int nleft = __builtin_amdgcn_readfirstlane(*s_cnt);
@@ -563,16 +613,17 @@ __global__ void profile_support_kernel(int rows, int nxs, const double* __restri
 
 template <int LP>
 static int launch_pruned_lp(hipStream_t stream, PrunedArgs G, int rows, size_t rows_per_launch) {
-    const size_t lds = (size_t)(2 + HMG_PRUNED_TWLDS) * LP * 16 + 32 * sizeof(double);
+    const size_t lds = pruned_lds_bytes<LP>();
+    G.lpt_nz = (rows_per_launch >= (size_t)rows && G.F.nm > 0 && rows % G.F.nm == 0) ? rows / G.F.nm : 0;
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void*)profile_pruned_kernel<FUSED_NT, LP>,
+        const hipError_t e = hipFuncSetAttribute((const void*)profile_pruned_kernel<LONG_NT, LP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     for (int r0 = 0; r0 < rows; r0 += (int)rows_per_launch) {
         const int nr = rows - r0 < (int)rows_per_launch ? rows - r0 : (int)rows_per_launch;
         G.row0 = r0;
-        hipLaunchKernelGGL((profile_pruned_kernel<FUSED_NT, LP>), dim3(nr), dim3(FUSED_NT), lds, stream, G);
+        hipLaunchKernelGGL((profile_pruned_kernel<LONG_NT, LP>), dim3(nr), dim3(LONG_NT), lds, stream, G);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }

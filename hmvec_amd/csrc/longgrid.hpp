@@ -8,18 +8,27 @@ namespace hmg {
 struct PrunedArgs {
     FusedArgs F;          // the row description (F.plan is not used)
     int M, R;             // packed length nxs/2 = R * LP
-    const cplx* twB;      // exp(-2 pi i t / M), t < M
-    const cplx* twL;      // exp(-2 pi i t / LP), t < LP
-    double* u;            // [rows of this launch][M]: u_j at [j-1]
+    const cplx* twB;      // exp(-2 pi i t / M), t < M (the narrow-band route's mode twiddles)
+    const cplx* twR;      // pruned route: the residues' twiddles on the samples, [s LP + p] = W_M^(s p) (ldsfft.hpp)
+    const UnpackTw* twNr; // pruned route: unpack constants by residue, [s (LP/2 + 1) + q] for mode s + R q
+    unsigned rmagic;      // 2^32 / R + 1: j / R of the residue-major scratch line
+    const cplx* twL;      // per-pass twiddle table of the sub-transform plan (length LP; the band route: LB)
+    double* u;            // [rows of this launch][M]: u_j, j = s + R q, at [s LP + q] (pruned_u_index)
     int* fault;           // set when a row's support turns out longer than LP (stale support bound)
     int row0;             // first row of this launch
     // chirp route for rows that need few modes (ldsfft.hpp; nullptr: every row takes the decomposition)
     const cplx* chP;      // ch(p), p < LP
     const cplx* chJ;      // ch(j), j <= Jw
     const cplx* Bw;       // transform of the chirp window / Lc, Lc = 2 LP
-    const cplx* twC;      // exp(-2 pi i t / Lc)
+    const cplx* twC;      // per-pass twiddle table of the length-Lc plan
     int Jw, p0;           // modes |j| <= Jw are in the window; it was built for supports of <= p0 packed samples
+    int lpt_nz;           // set by launch_pruned: redshifts of a launch that covers whole redshifts (heavy rows first), else 0
 };
+
+#ifndef HMG_LONG_NT
+#define HMG_LONG_NT 512
+#endif
+constexpr int LONG_NT = HMG_LONG_NT;   // threads per row workgroup of the pruned long-grid kernel
 
 // sub-transform lengths LP that are compiled in
 bool pruned_lp_compiled(int LP);

@@ -128,12 +128,12 @@ static int pruned_rfft_imag(const double* y, int n, int nthreads, int jn, double
     for (int i = 2 * LP; i < n; ++i)
         if (y[i] != 0.0) return 4;
     const long double twopi = 6.283185307179586476925286766559L;
-    std::vector<cplx> twB(M), twL(LP), src(LP), buf(2 * (size_t)LP, cplx{1.0e30, -1.0e30});
-    std::vector<UnpackTw> twN(M / 2 + 1);
-    for (int t = 0; t < M; ++t) twB[t] = {(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
-    for (int t = 0; t < LP; ++t) twL[t] = {(double)cosl(twopi * t / LP), (double)-sinl(twopi * t / LP)};
-    for (int j = 0; j <= M / 2; ++j)
-        twN[j] = UnpackTw{(double)cosl(twopi * j / n), (double)sinl(twopi * j / n), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
+    (void)twopi;
+    std::vector<cplx> src(LP), buf(2 * (size_t)LP, cplx{1.0e30, -1.0e30});
+    // the tables as the library lays them out: twiddles per pass, residue twiddles and unpack constants by residue
+    const std::vector<cplx> twL = pass_tw_table(SubPass<LP, 0>::P), twR = residue_tw_table(M, LP);
+    const std::vector<UnpackTw> twNr = residue_unpack_table(M, LP);
+    const unsigned rmagic = (unsigned)(4294967296ull / (unsigned)R) + 1u;
     for (int p = 0; p < LP; ++p) src[p] = {y[2 * p], y[2 * p + 1]};
     std::vector<double> u(M, NAN);
     constexpr int nb_last = SubPass<LP, SubPass<LP, 0>::P.npass - 1>::nb;
@@ -148,20 +148,20 @@ static int pruned_rfft_imag(const double* y, int n, int nthreads, int jn, double
                     for (int hb = 0; hb < nbuf; ++hb) {
                         const int sres = hb ? s1 : g;
                         cplx v[S0::R];
-                        for (int t = 0; t < S0::R; ++t) v[t] = cmul(src[jb + t * S0::nb], twB[sres * (jb + t * S0::nb)]);
+                        for (int t = 0; t < S0::R; ++t) v[t] = cmul(src[jb + t * S0::nb], twR[(size_t)sres * LP + jb + t * S0::nb]);
                         dft_small<S0::R>(v);
                         for (int t = 0; t < S0::R; ++t) buf[hb * LP + jb * S0::R + t] = v[t];
                     }
         }
         run_sub_passes<LP, 1>(buf, twL, nbuf, pruned_keep(R, M, nb_last, jn), nthreads);
         for (int tid = 0; tid < nthreads; ++tid) {
-            pruned_unpack(buf.data(), LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, twN.data(), 1.0, u.data(), tid, nthreads);
-            if (nbuf == 2) pruned_unpack(buf.data(), LP, R, M, s1, 1, 0, jn, twN.data(), 1.0, u.data(), tid, nthreads);
+            pruned_unpack(buf.data(), LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, twNr.data(), 1.0, u.data(), tid, nthreads);
+            if (nbuf == 2) pruned_unpack(buf.data(), LP, R, M, s1, 1, 0, jn, twNr.data(), 1.0, u.data(), tid, nthreads);
         }
     }
     imF[0] = 0.0;
     imF[M] = 0.0;
-    for (int j = 1; j < M; ++j) imF[j] = u[j - 1] * j;
+    for (int j = 1; j < M; ++j) imF[j] = u[pruned_u_index(R, LP, rmagic, j)] * j;      // the line is laid out by residue
     return 0;
 }
 extern "C" int ldsfft_pruned_rfft_imag(const double* y, int n, int LP, int nthreads, int jn, double* imF /* n/2+1 */) {
@@ -212,8 +212,8 @@ static int chirp_rfft_imag(const double* y, int n, int p0, int nwin, int nthread
     const ChirpTables T = chirp_make_tables(M, LC, p0, nwin);
     if (jn > T.Jw + T.nwin * T.Kp) return 5;
     const long double twopi = 6.283185307179586476925286766559L;
-    std::vector<cplx> tw(LC), buf(LC, cplx{1.0e30, -1.0e30});
-    for (int t = 0; t < LC; ++t) tw[t] = {(double)cosl(twopi * t / LC), (double)-sinl(twopi * t / LC)};
+    std::vector<cplx> buf(LC, cplx{1.0e30, -1.0e30});
+    const std::vector<cplx> tw = pass_tw_table(C0::P);
     constexpr int nb0 = C0::nb;                          // = LP / 2
     constexpr int nb_last = SubPass<LC, C0::P.npass - 1>::nb;
     for (int jb = 0; jb < nb0; ++jb) {
@@ -282,9 +282,9 @@ static int band_rfft_imag(const double* y, int n, int nthreads, int jn, double* 
     const int D = M / LB;
     if (2 * jn + 2 > LB) return 5;
     const long double twopi = 6.283185307179586476925286766559L;
-    std::vector<cplx> twB(M), twL(LB), buf(LB, cplx{1.0e30, -1.0e30});
+    std::vector<cplx> twB(M), buf(LB, cplx{1.0e30, -1.0e30});
+    const std::vector<cplx> twL = pass_tw_table(S0::P);
     for (int t = 0; t < M; ++t) twB[t] = {(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
-    for (int t = 0; t < LB; ++t) twL[t] = {(double)cosl(twopi * t / LB), (double)-sinl(twopi * t / LB)};
     const int nacc = 2 * jn + 1;
     std::vector<cplx> acc(nacc, cplx{0.0, 0.0}), wcur(nacc, cplx{1.0, 0.0}), wstep(nacc);
     for (int t = 0; t < nacc; ++t) {
