@@ -1134,7 +1134,7 @@ __device__ __forceinline__ void fused_passes_ct(cplx* buf, const cplx* __restric
         constexpr int MAXB = (S::nb + NT - 1) / NT;
         // the last pass only has to produce Z[0..jn] and Z[M-jn..M-1]
         const int keep = (S::last && 2 * jn + 2 < S::nb) ? jn : -1;
-        if (!(PS == 0 && pruned)) fused_pass<NT, S::R, MAXB, S::SMALL>(buf, twM, M, S::Ns, S::tws, S::mg, keep);
+        if (!(PS == 0 && pruned)) fused_pass<NT, S::R, MAXB, S::SMALL>(buf, twM + S::twoff, M, S::Ns, 1, S::mg, keep);
         fused_passes_ct<NT, M, PS + 1>(buf, twM, pruned, jn);
     }
 }
@@ -1308,30 +1308,33 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     if constexpr (SPECM == 2500) {
         // butterfly indices stay below 1024: the 24-bit index arithmetic of ldsfft.hpp (div_ns)
         constexpr unsigned mg4 = small_magic(4), mg20 = small_magic(20), mg100 = small_magic(100), mg500 = small_magic(500);
-        if (!pruned) fused_pass<NT, 4, MAXB, true>(buf, A.twM, 2500, 1, 625, 0u, -1);
+        // (A.twM is the per-pass twiddle table, ldsfft.hpp: the slices of the passes start at 0, 1, 5, 25, 125 and a
+        // butterfly reads element k = j mod Ns of its pass's slice - consecutive lanes, consecutive elements)
+        if (!pruned) fused_pass<NT, 4, MAXB, true>(buf, A.twM, 2500, 1, 1, 0u, -1);
         // behind the pruned first pass slot i of the row holds sample i/4: a butterfly of this pass reads slots
         // j + 500 t, and those with t >= 3 are zero when the row is zero from sample 1500/4 on (cmax < 3 at xmax = 20)
         if (pruned) {
-            if (lead3) fused_pass<NT, 5, 1, true, 3, 2>(buf, A.twM, 2500, 4, 125, mg4, -1);
-            else fused_pass<NT, 5, 1, true, 5, 2>(buf, A.twM, 2500, 4, 125, mg4, -1);
-        } else fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 4, 125, mg4, -1);
-        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 20, 25, mg20, -1);
-        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 100, 5, mg100, -1);
-        fused_pass<NT, 5, 1, true>(buf, A.twM, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
+            if (lead3) fused_pass<NT, 5, 1, true, 3, 2>(buf, A.twM + 1, 2500, 4, 1, mg4, -1);
+            else fused_pass<NT, 5, 1, true, 5, 2>(buf, A.twM + 1, 2500, 4, 1, mg4, -1);
+        } else fused_pass<NT, 5, 1, true>(buf, A.twM + 1, 2500, 4, 1, mg4, -1);
+        fused_pass<NT, 5, 1, true>(buf, A.twM + 5, 2500, 20, 1, mg20, -1);
+        fused_pass<NT, 5, 1, true>(buf, A.twM + 25, 2500, 100, 1, mg100, -1);
+        fused_pass<NT, 5, 1, true>(buf, A.twM + 125, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
     } else if constexpr (SPECM != 0) {
         fused_passes_ct<NT, SPECM, 0>(buf, A.twM, pruned, jn);
     } else
     for (int ps = pruned ? 1 : 0; ps < A.plan.npass; ++ps) {
-        const int R = A.plan.radix[ps], Ns = A.plan.ns[ps], tws = A.plan.twstep[ps];
+        const int R = A.plan.radix[ps], Ns = A.plan.ns[ps], tws = 1;      // (per-pass twiddle table: element k of the slice)
         const unsigned mg = A.plan.magic[ps];
+        const cplx* __restrict__ twp = A.twM + A.plan.twoff[ps];
         // a pass whose butterflies fit one per thread uses the MAXB = 1 body (fewer live registers)
         const bool one = (M / R) <= NT;
         // the last pass only has to produce Z[0..jn] and Z[M-jn..M-1]
         const int keep = (ps == A.plan.npass - 1 && 2 * jn + 2 < M / R) ? jn : -1;
-        if (R == 5) { if (one) fused_pass<NT, 5, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 5, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
-        else if (R == 4) { if (one) fused_pass<NT, 4, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 4, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
-        else if (R == 3) { if (one) fused_pass<NT, 3, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 3, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
-        else { if (one) fused_pass<NT, 2, 1>(buf, A.twM, M, Ns, tws, mg, keep); else fused_pass<NT, 2, MAXB>(buf, A.twM, M, Ns, tws, mg, keep); }
+        if (R == 5) { if (one) fused_pass<NT, 5, 1>(buf, twp, M, Ns, tws, mg, keep); else fused_pass<NT, 5, MAXB>(buf, twp, M, Ns, tws, mg, keep); }
+        else if (R == 4) { if (one) fused_pass<NT, 4, 1>(buf, twp, M, Ns, tws, mg, keep); else fused_pass<NT, 4, MAXB>(buf, twp, M, Ns, tws, mg, keep); }
+        else if (R == 3) { if (one) fused_pass<NT, 3, 1>(buf, twp, M, Ns, tws, mg, keep); else fused_pass<NT, 3, MAXB>(buf, twp, M, Ns, tws, mg, keep); }
+        else { if (one) fused_pass<NT, 2, 1>(buf, twp, M, Ns, tws, mg, keep); else fused_pass<NT, 2, MAXB>(buf, twp, M, Ns, tws, mg, keep); }
     }
     if constexpr (ABL == 2) {     // stop after phase B
         if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[24];
@@ -3456,10 +3459,11 @@ static int get_fused_plan(hmg_ctx* c, int nxs, FusedPlan** out) {
         c->fused[nxs] = FusedPlan();  // remember the rejection
         return 0;
     }
-    std::vector<cplx> twM(M);
+    // twiddles per pass (ldsfft.hpp: pass_tw_table): element k of a pass's slice is W_M^(k twstep), so that
+    // consecutive butterflies read consecutive elements instead of gathering at a stride of twstep from one table
+    const std::vector<cplx> twM = pass_tw_table(P.plan);
     std::vector<UnpackTw> twN(M / 2 + 1);
     const long double twopi = 6.283185307179586476925286766559L;
-    for (int t = 0; t < M; ++t) twM[t] = cplx{(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
     for (int j = 0; j <= M / 2; ++j)
         twN[j] = UnpackTw{(double)cosl(twopi * j / nxs), (double)sinl(twopi * j / nxs), j ? 1.0 / j : 0.0, 1.0 / (M - j)};
     HIP_TRY(hipMalloc((void**)&P.twM, twM.size() * sizeof(cplx)));

@@ -40,6 +40,7 @@ struct FftPlanDev {
     int ns[FFT_MAX_PASSES];
     int twstep[FFT_MAX_PASSES];
     unsigned magic[FFT_MAX_PASSES];
+    int twoff[FFT_MAX_PASSES];    // start of the pass's slice in the per-pass twiddle table (pass_tw_table): sum of the earlier Ns
 };
 
 // j / d for 0 <= j < 2^16, 1 < d < 2^16 with magic = floor(2^32 / d) + 1 (magic = 0 encodes d == 1)
@@ -119,6 +120,7 @@ constexpr bool fft_plan_fill(int M, FftPlanDev& p) {
         p.ns[i] = Ns;
         p.twstep[i] = M / (Ns * p.radix[i]);
         p.magic[i] = Ns == 1 ? 0u : (unsigned)(4294967296ull / (unsigned)Ns) + 1u;
+        p.twoff[i] = i ? p.twoff[i - 1] + p.ns[i - 1] : 0;
         Ns *= p.radix[i];
     }
     return rem == 1 && M >= 2 && M < 65536;

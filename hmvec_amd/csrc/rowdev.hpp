@@ -44,7 +44,7 @@ struct FusedArgs {
     FftPlanDev plan;
     int nxs, nm, nk, do_norm;
     const double* xs;
-    const cplx* twM;     // exp(-2 pi i t / M), t < M
+    const cplx* twM;     // per-pass twiddle table of the plan (ldsfft.hpp: pass_tw_table)
     const UnpackTw* twN; // (cos, sin)(2 pi j / nxs), 1/j, 1/(M-j) for j <= M/2
     const double* kts;
     const double *amp, *xc, *alpha, *expo;
