@@ -373,6 +373,9 @@ __global__ __launch_bounds__(NT, (pruned_occ<NT, LP>())) void profile_pruned_ker
 // lie in memory that is one 16-byte piece per 64-byte line and lane.  One small launch per profile call lays the three
 // out the way the row kernel walks them - pair (p1, p2) at [p1 LB + p2], p = p1 + D p2 - so that a wavefront's loads are
 // contiguous again (G.u holds the tables: 3 nxs doubles).  w_n = (x_{n+1} - x_{n-1})/2 with the one-sided ends of np.trapz.
+#ifndef HMG_BAND_NBUF
+#define HMG_BAND_NBUF 2
+#endif
 __global__ void band_tables_kernel(int nxs, int D, int LB, const double* __restrict__ xs, const double* __restrict__ logx,
                                    double2* __restrict__ xT, double2* __restrict__ lT, double2* __restrict__ wT) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;       // q = p1 LB + p2
@@ -386,13 +389,22 @@ __global__ void band_tables_kernel(int nxs, int D, int LB, const double* __restr
     wT[q] = make_double2(0.5 * (x1 - xl), 0.5 * (xr - x0));
 }
 
+constexpr bool defined_abl8() {
+#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 8)      // timing experiment: without the accumulation of the band's modes
+    return true;
+#else
+    return false;
+#endif
+}
 template <int NT, int LB, int MAXA>
 __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, double* smem) {
     const FusedArgs& A = G.F;
-    // dynamic LDS: [0, LB) cplx = the transform buffer (later the band's modes), then LB/2 doubles of u_j, then 32
-    // doubles of scalars laid out as in profile_fused_row
+    // dynamic LDS: [0, NBUF LB) cplx = the transform buffers (later the band's modes), then LB/2 doubles of u_j, then
+    // 32 doubles of scalars laid out as in profile_fused_row.  Two residues p1, p1 + 1 of the sample index are
+    // transformed side by side (HMG_BAND_NBUF = 2): every thread has a butterfly in every pass and a row passes
+    // half as many barriers as with one buffer.
     cplx* buf = reinterpret_cast<cplx*>(smem);
-    double* us = smem + 2 * (size_t)LB;
+    double* us = smem + 2 * (size_t)LB * HMG_BAND_NBUF;
     double* red = us + LB / 2 + (LB / 2 & 1);
     int* s_cnt = reinterpret_cast<int*>(red + 17);
     int* s_jn = reinterpret_cast<int*>(red + 18);
@@ -409,6 +421,9 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
     const double EX = A.expo ? A.expo[row] : A.expo_c;
     const double cm = A.cmax[row];
     const double ln_xc = (A.xc == nullptr && A.xc_c == 1.0) ? 0.0 : log_fast(XC);
+    // alpha == 1 for every row (the pressure profile this route was built for): t^alpha = x / xc, no exponential
+    const bool alpha1 = A.alpha == nullptr && A.alpha_c == 1.0;
+    const double inv_xc = fm_rcp(XC);
     const int z = row / A.nm;
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
     // row scalars and the end of the left-fill prefix: the last wavefront, as in profile_fused_row (hints are a
@@ -472,40 +487,63 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
     const double2* __restrict__ lT = xT + M;
     const double2* __restrict__ wT = lT + M;
     double nrm = 0.0;
-    for (int p1 = 0; p1 < D; ++p1) {
-        // first pass (radix R0, sub-transform size 1) of the decimated row z[p1 + D p2], straight from the integrand
+    for (int p1 = 0; p1 < D; p1 += HMG_BAND_NBUF) {
+        const int nbuf = (HMG_BAND_NBUF == 2 && p1 + 1 < D) ? 2 : 1;
+        // first pass (radix R0, sub-transform size 1) of the decimated rows z[p1 + h + D p2], straight from the integrand
 #pragma unroll
-        for (int b = 0; b < MAXB0; ++b) {
-            const int jb = threadIdx.x + b * NT;
-            if (jb < nb0) {
-                cplx v[R0];
+        for (int h = 0; h < HMG_BAND_NBUF; ++h) {
+            if (h < nbuf) {
 #pragma unroll
-                for (int t = 0; t < R0; ++t) {
-                    const int q = p1 * LB + jb + t * nb0;                       // pair p = p1 + D p2, p2 = jb + t nb0
-                    const double2 xv = xT[q], lv = lT[q], wv = wT[q];
-                    double r0 = 0.0, r1 = 0.0;
-                    if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(lv.x - ln_xc, Aamp, AL, EX, A.gamma);
-                    if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(lv.y - ln_xc, Aamp, AL, EX, A.gamma);
-                    v[t] = cplx{xv.x * r0, xv.y * r1};
-                    if (A.do_norm && (r0 != 0.0 || r1 != 0.0))
-                        nrm += wv.x * (r0 * (xv.x * xv.x)) + wv.y * (r1 * (xv.y * xv.y));
+                for (int b = 0; b < MAXB0; ++b) {
+                    const int jb = threadIdx.x + b * NT;
+                    if (jb < nb0) {
+                        cplx v[R0];
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) {
+                            const int q = (p1 + h) * LB + jb + t * nb0;             // pair p = p1 + h + D p2, p2 = jb + t nb0
+                            const double2 xv = xT[q], lv = lT[q], wv = wT[q];
+                            double r0 = 0.0, r1 = 0.0;
+#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 64)     // timing experiment: no transcendentals in the integrand
+                            if (!(fabs(xv.x) > cm)) r0 = Aamp * lv.x + AL;
+                            if (!(fabs(xv.y) > cm)) r1 = Aamp * lv.y + EX;
+#else
+                            if (alpha1) {
+                                if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_alpha1(lv.x - ln_xc, xv.x * inv_xc, Aamp, EX, A.gamma);
+                                if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_alpha1(lv.y - ln_xc, xv.y * inv_xc, Aamp, EX, A.gamma);
+                            } else {
+                                if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(lv.x - ln_xc, Aamp, AL, EX, A.gamma);
+                                if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(lv.y - ln_xc, Aamp, AL, EX, A.gamma);
+                            }
+#endif
+                            v[t] = cplx{xv.x * r0, xv.y * r1};
+                            if (A.do_norm && (r0 != 0.0 || r1 != 0.0))
+                                nrm += wv.x * (r0 * (xv.x * xv.x)) + wv.y * (r1 * (xv.y * xv.y));
+                        }
+                        dft_small<R0>(v);
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) buf[h * LB + jb * R0 + t] = v[t];
+                    }
                 }
-                dft_small<R0>(v);
-#pragma unroll
-                for (int t = 0; t < R0; ++t) buf[jb * R0 + t] = v[t];
             }
         }
         __syncthreads();
-        pruned_passes<NT, LB, 1, 1>(buf, G.twL, 1, keep);
+#if !(defined(HMG_LG_ABL) && (HMG_LG_ABL & 4))   // timing experiment: without the passes in LDS
+        pruned_passes<NT, LB, 1, HMG_BAND_NBUF>(buf, G.twL, nbuf, keep);
+#endif
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
             const int t = threadIdx.x + a * NT;
-            if (t < nslot) {
-                acc[a] = cadd(acc[a], cmul(buf[band_index(band_mode(t, jn), LB)], wcur[a]));
+            if (t < nslot && !(defined_abl8())) {
+                const int idx = band_index(band_mode(t, jn), LB);
+                acc[a] = cadd(acc[a], cmul(buf[idx], wcur[a]));                    // residue p1 ...
                 wcur[a] = cmul(wcur[a], wstep[a]);
+                if (nbuf == 2) {
+                    acc[a] = cadd(acc[a], cmul(buf[LB + idx], wcur[a]));           // ... then p1 + 1: the same order of sums
+                    wcur[a] = cmul(wcur[a], wstep[a]);
+                }
             }
         }
-        __syncthreads();                                       // the next residue's first pass overwrites the buffer
+        __syncthreads();                                       // the next residues' first pass overwrites the buffers
     }
     // mass norm (the order of the partial sums differs from the one-row kernel: per thread over its samples of all
     // residues, then wavefronts in order) and the scale of the unpack step
@@ -662,7 +700,7 @@ static int launch_band_lb(hipStream_t stream, PrunedArgs G, int rows, int jnmax)
                        G.F.logx, tb, tb + M, tb + 2 * (size_t)M);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const size_t lds = (size_t)LB * 16 + (size_t)(LB / 2 + 2) * 8 + 32 * sizeof(double);
+    const size_t lds = (size_t)HMG_BAND_NBUF * LB * 16 + (size_t)(LB / 2 + 2) * 8 + 32 * sizeof(double);
     if (2 * jnmax + 1 <= FUSED_NT)
         hipLaunchKernelGGL((profile_band_kernel<FUSED_NT, LB, 1>), dim3(rows), dim3(FUSED_NT), lds, stream, G);
     else

@@ -66,4 +66,11 @@ __device__ __forceinline__ double gnfw_rho_fast(double lt /* ln(x/xc) */, double
     return A * exp_fast<false>(gamma * lt - EX * log1p_abs(ta));
 }
 
+// The member with alpha == 1 (the Battaglia pressure profile, hmvec/hmvec.py:906-927 with battaglia_pres_alpha = 1):
+// t^alpha is t = x / xc itself - one exponential per sample instead of two.
+__device__ __forceinline__ double gnfw_rho_alpha1(double lt /* ln(x/xc) */, double t /* x/xc */, double A, double EX,
+                                                  double gamma) {
+    return A * exp_fast<false>(gamma * lt - EX * log1p_abs(t));
+}
+
 }  // namespace hmg
