@@ -328,6 +328,8 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
             c2 = nat.Context(ctx.device)          # the route switches are read when a context is created
             h2 = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic", ctx=c2)
             n = reps if route != "rocfft" else 3
+            o1 = [c2.empty((zs.size, ks.size)) for _ in pairs]      # result buffers of every pass (a captured pass allocates nothing)
+            o2 = [c2.empty((zs.size, ks.size)) for _ in pairs]
 
             def one(timed):
                 h2.init_mass_function(ms)
@@ -336,7 +338,7 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
                     c2.call("hmg_bracket_next", nat.KERNEL_PROFILE_FFT, 44, 45)
                 h2.add_battaglia_profile("electron", family="AGN", xmax=50, nxs=30000, ignore_existing=True)
                 h2.add_hod("g", mthresh=mthr, ignore_existing=True)
-                return h2.power_device_batch(pairs)
+                return h2.power_device_batch(pairs, outs1=o1, outs2=o2)
             one(False); one(False)
             c2.sync()
             t_fft = []
@@ -347,6 +349,31 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
                 t_fft.append(c2.elapsed_ms(44, 45))
             wall = (time.perf_counter() - t0) / n * 1e3
             out[route] = {"profile_stage_ms": float(np.median(t_fft)), "pass_wall_ms_eager": wall}
+            if route == "pruned":
+                # the same pass as ONE captured step, replayed: the number that compares with the headline ms_per_step
+                gid = c2.capture(lambda: one(False))
+                for _ in range(3):
+                    c2.replay(gid)
+                c2.sync()
+                K = 20
+                c2.record(46)
+                for _ in range(K):
+                    c2.replay(gid)
+                c2.record(47)
+                c2.sync()
+                out["ms_per_step"] = c2.elapsed_ms(46, 47) / K
+                out["ms_per_step_note"] = (f"HIP-graph replay of the whole pass with this profile, {K} replays between two events "
+                                           "(the headline step with nxs = 5000 is timed the same way)")
+                # the numeric NFW branch at the reference's defaults (hmvec/params.py:59-60): nxs = 40000, xmax = 200
+                t_ = []
+                for i in range(2 + 5):
+                    c2.call("hmg_bracket_next", nat.KERNEL_PROFILE_FFT, 44, 45)
+                    h2.add_nfw_profile("nfwnum", numeric=True, ignore_existing=True)
+                    c2.sync()
+                    if i >= 2:
+                        t_.append(c2.elapsed_ms(44, 45))
+                out["numeric_nfw"] = {"profile": "add_nfw_profile(numeric=True): nxs=40000, xmax=200 (hmvec/params.py:59-60)",
+                                      "profile_stage_ms": float(np.median(t_))}
             if route != "pruned_no_chirp":
                 tens[route] = h2.uk_profiles["electron"][::4, ::16]      # a strided sample of the (nz,nm,nk) tensor
             del h2

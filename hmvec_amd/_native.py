@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 6
+ABI_VERSION = 7
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -134,6 +134,7 @@ SIGNATURES = {
     "hmg_graph_launch": [_P, _I],
     "hmg_graph_destroy": [_P, _I],
     "hmg_lane_set": [_P, _I],
+    "hmg_profile_support_epoch": [_P, C.c_longlong],
     "hmg_event_wait": [_P, _I],
     "hmg_event_record": [_P, _I],
     "hmg_elapsed_ms": [_P, _I, _I, C.POINTER(_D)],
@@ -421,7 +422,7 @@ class Context:
         check(self.lib.hmg_elapsed_ms(self.handle, s0, s1, C.byref(ms)))
         return ms.value
 
-    _NO_FLUSH = frozenset(["hmg_bracket_next"])      # calls that enqueue nothing and read nothing
+    _NO_FLUSH = frozenset(["hmg_bracket_next", "hmg_profile_support_epoch"])      # calls that enqueue nothing and read nothing
 
     def call(self, name, *args):
         if name not in self._NO_FLUSH:

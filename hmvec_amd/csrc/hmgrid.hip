@@ -95,11 +95,12 @@ struct ChirpPlan {                        // tables of the chirp route (ldsfft.h
     hmg::cplx *chP = nullptr, *chJ = nullptr, *Bw = nullptr;
     int Jw = 0;
 };
-struct SupportKey {
-    const void *cmax, *xs;
-    int rows, nxs;
+struct SupportKey {                       // what a measured bound on a launch's rows was measured for
+    const void *cmax, *xs, *rss, *ks;
+    int rows, nxs, nk;
+    long long epoch;                      // the caller's tag of the arrays' CONTENTS (hmg_profile_support_epoch), 0 = none
     bool operator<(const SupportKey& o) const {
-        return std::tie(cmax, xs, rows, nxs) < std::tie(o.cmax, o.xs, o.rows, o.nxs);
+        return std::tie(cmax, xs, rss, ks, rows, nxs, nk, epoch) < std::tie(o.cmax, o.xs, o.rss, o.ks, o.rows, o.nxs, o.nk, o.epoch);
     }
 };
 
@@ -123,13 +124,17 @@ struct hmg_ctx {
     int pruned_lp_min = 0;                         // HMG_PRUNED_LP_MIN: smallest sub-transform length to consider
     int use_chirp = 1;                             // HMG_CHIRP=0: every row of a long grid takes the decomposition
     int use_band_fft = 1;                          // HMG_BAND_FFT=0: supports that do not prune go to rocFFT
+    int fused_generic = 0;                         // HMG_FUSED_GENERIC=1 (testing): the run-time plan for every one-row length
     std::map<std::tuple<int, int, int>, ChirpPlan> chirp;   // (nxs, LP, p0) -> tables
     std::map<std::pair<int, int>, PrunedPlan> pruned;   // (nxs, LP) -> tables of the long-grid routes
     std::map<int, hmg::cplx*> pass_tw;             // L -> per-pass twiddle table of the length-L plan (ldsfft.hpp)
     std::map<SupportKey, std::pair<int, int>> support;   // last measured bounds of a launch's rows: (support in packed samples, needed modes)
-    int* d_fault = nullptr;                        // device word a kernel raises when it cannot do what it was launched for
-    int* h_fault = nullptr;                        // its pinned host twin
-    bool fault_armed = false;                      // a kernel that may raise it ran since the last check
+    // word a kernel raises when it cannot do what it was launched for: ONE word in page-locked host memory that the
+    // device writes directly (a system-scope store), so that a host that has waited for the kernel - through whichever
+    // stream, lane or event - reads it without a copy and without a question of which stream the copy belongs to
+    int* h_fault = nullptr;
+    int* d_fault = nullptr;                        // the device's address of the same word
+    long long support_epoch = 0;                   // hmg_profile_support_epoch: tag of the contents of cmax / rss / ks arrays
     int sig_nz = 0, sig_nm = 0, sig_nq = 0;        // shape of the partial sums the last sigma^2 contraction left in scratch[4]
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
@@ -174,18 +179,11 @@ static int event_at(hmg_ctx* c, int slot, hipEvent_t* out) {
 // A kernel that finds it cannot do what it was launched for (a row whose support exceeds the plan the launch was
 // sized for) raises the context's fault word instead of writing wrong numbers quietly; synchronising calls report it.
 static int check_fault(hmg_ctx* c) {
-    if (!c->fault_armed) return 0;
-    c->fault_armed = false;
-    HIP_TRY(hipMemcpyAsync(c->h_fault, c->d_fault, sizeof(int), hipMemcpyDeviceToHost, c->lanes[0]));
-    HIP_TRY(hipStreamSynchronize(c->lanes[0]));
-    if (*c->h_fault) {
-        *c->h_fault = 0;
-        HIP_TRY(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->lanes[0]));
-        c->support.clear();
-        return fail("device fault", "a profile row's support exceeded the bound its launch was sized for (the rows were "
-                    "filled with NaN); the cached bound is dropped - run the step eagerly again", __FILE__, __LINE__);
-    }
-    return 0;
+    if (!*(volatile int*)c->h_fault) return 0;
+    *(volatile int*)c->h_fault = 0;
+    c->support.clear();
+    return fail("device fault", "a profile row's support exceeded the bound its launch was sized for (the rows were "
+                "filled with NaN); the cached bound is dropped - run the step eagerly again", __FILE__, __LINE__);
 }
 static int sync_all(hmg_ctx* c) {
     REQUIRE(!c->capturing, "this call synchronises the device and cannot be part of a captured step");
@@ -2755,10 +2753,10 @@ static int ctx_init(hmg_ctx* c, int device) {
     if (const char* s = getenv("HMG_PRUNED_LP_MIN")) c->pruned_lp_min = atoi(s);
     if (const char* s = getenv("HMG_CHIRP")) c->use_chirp = atoi(s);
     if (const char* s = getenv("HMG_BAND_FFT")) c->use_band_fft = atoi(s);
-    HIP_TRY(hipMalloc((void**)&c->d_fault, sizeof(int)));
-    HIP_TRY(hipMemset(c->d_fault, 0, sizeof(int)));
-    HIP_TRY(hipHostMalloc((void**)&c->h_fault, sizeof(int), hipHostMallocDefault));
+    if (getenv("HMG_FUSED_GENERIC")) c->fused_generic = 1;
+    HIP_TRY(hipHostMalloc((void**)&c->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent));
     *c->h_fault = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->d_fault, c->h_fault, 0));
     if (const char* s = getenv("HMG_FFT_CHUNK_MB")) c->fft_chunk_bytes = (size_t)atol(s) << 20;
     return 0;
 }
@@ -2810,7 +2808,6 @@ int hmg_ctx_destroy(hmg_ctx* c) {
         if (kv.second.twNr) (void)hipFree(kv.second.twNr);
     }
     for (auto& kv : c->pass_tw) (void)hipFree(kv.second);
-    if (c->d_fault) (void)hipFree(c->d_fault);
     if (c->h_fault) (void)hipHostFree(c->h_fault);
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
@@ -2913,7 +2910,7 @@ int hmg_event_synchronize(hmg_ctx* c, int slot) {
     REQUIRE(!c->capturing, "hmg_event_synchronize inside a captured step");
     REQUIRE(c->ev[slot] != nullptr, "event slot was never recorded");
     HIP_TRY(hipEventSynchronize(c->ev[slot]));
-    return 0;
+    return check_fault(c);      // (the streamed hand-over of results waits here and nowhere else)
 }
 constexpr size_t PIN_CHUNK = (size_t)8 << 20;   // 8 MiB per bounce buffer
 
@@ -3121,7 +3118,6 @@ int hmg_graph_launch(hmg_ctx* c, int id) {
     auto it = c->graphs.find(id);
     REQUIRE(it != c->graphs.end(), "unknown graph id");
     HIP_TRY(hipGraphLaunch(it->second, c->stream));
-    if (!c->pruned.empty()) c->fault_armed = true;    // the graph may hold a launch that can raise the fault word
     return 0;
 }
 int hmg_graph_destroy(hmg_ctx* c, int id) {
@@ -3575,17 +3571,23 @@ static int get_chirp_plan(hmg_ctx* c, int nxs, int LP, int p0, ChirpPlan** out) 
     return 0;
 }
 
-// Support bound of a launch's rows in packed samples.  Eager calls measure it (one small kernel, a 4-byte copy);
-// inside a captured step the value of the last eager call with the same arrays is used - what a replay computes
-// is what was captured - and the kernel itself re-checks every row (fault word).
-static int profile_support(hmg_ctx* c, int rows, const FusedArgs& A, int* p0max, int* jnmax) {
-    const SupportKey key{A.cmax, A.xs, rows, A.nxs};
-    if (c->capturing) {
+// Support bound of a launch's rows in packed samples, and the bound on the modes they need.  A call measures them (one
+// small kernel, a 4-byte copy, a stream synchronisation) unless a bound measured for the same arrays is on file AND the
+// contents of those arrays are known not to have changed: inside a captured step (what a replay computes is what was
+// captured), or when the caller has tagged the contents (hmg_profile_support_epoch != 0: the facade tags them per
+// model and mass grid) - eager calls of a model then cost no host synchronisation after the first.  Every row
+// re-checks itself against the bound its launch was sized for (fault word).  *known = 0: nothing on file inside a capture.
+static int profile_support(hmg_ctx* c, int rows, const FusedArgs& A, int* p0max, int* jnmax, int* known) {
+    const SupportKey key{A.cmax, A.xs, A.nconst ? A.rss : nullptr, A.nconst ? A.ks : nullptr, rows, A.nxs, A.nk, c->support_epoch};
+    *known = 1;
+    if (c->capturing || c->support_epoch != 0) {
         auto it = c->support.find(key);
-        REQUIRE(it != c->support.end(), "profile support bound unknown inside a captured step: run the step once eagerly first");
-        *p0max = it->second.first;
-        *jnmax = it->second.second;
-        return 0;
+        if (it != c->support.end()) {
+            *p0max = it->second.first;
+            *jnmax = it->second.second;
+            return 0;
+        }
+        if (c->capturing) { *known = 0; return 0; }
     }
     if (ensure_scratch(c, 2, 64)) return 1;
     int* d_p0 = (int*)c->scratch[2];
@@ -3597,23 +3599,29 @@ static int profile_support(hmg_ctx* c, int rows, const FusedArgs& A, int* p0max,
     HIP_TRY(hipMemcpyAsync(h, d_p0, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!A.nconst) h[1] = A.nxs / 2;
-    if (c->support.size() >= 256) c->support.clear();     // (keyed by addresses: bounded, and a dropped entry only costs
-    c->support[key] = std::make_pair(h[0], h[1]);          //  a captured step its bounds - the eager call before it refills)
+    if (c->support.size() >= 256) c->support.clear();     // (bounded; a dropped entry costs one more measurement)
+    c->support[key] = std::make_pair(h[0], h[1]);
     *p0max = h[0];
     *jnmax = h[1];
     return 0;
 }
 
 // Returns 0 and *taken = 1 when the pruned route ran, *taken = 0 when the launch is not one it can take.
-static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* taken) {
+// can_fall_back: the caller has another route for this length (one row in LDS), so an unknown bound inside a captured
+// step is no error.
+static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, bool can_fall_back, int* taken) {
     *taken = 0;
     const int nxs = A0.nxs, M = nxs / 2;
     if ((nxs & 1) || M < 2 * PRUNED_LP[0]) return 0;
     bool any = false;
     for (int lp : PRUNED_LP) any = any || (M % lp == 0 && M / lp >= 2);
     if (!any) return 0;
-    int p0max = 0, jnmax = 0;
-    if (profile_support(c, rows, A0, &p0max, &jnmax)) return 1;
+    int p0max = 0, jnmax = 0, known = 1;
+    if (profile_support(c, rows, A0, &p0max, &jnmax, &known)) return 1;
+    if (!known) {
+        REQUIRE(can_fall_back, "profile support bound unknown inside a captured step: run the step once eagerly first");
+        return 0;
+    }
     int LP = 0;
     const int lp_min = c->pruned_lp_min > p0max ? c->pruned_lp_min : p0max;     // (HMG_PRUNED_LP_MIN: tuning / tests)
     for (int lp : PRUNED_LP)
@@ -3642,7 +3650,6 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
         int stop = -1;
         if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
         HIP_TRY((hipError_t)launch_band(c->stream, LB, G, rows, jnmax));
-        c->fault_armed = true;
         *taken = 1;
         return bracket_close(c, stop);
     }
@@ -3677,7 +3684,6 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, int* ta
     int stop = -1;
     if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
     HIP_TRY((hipError_t)launch_pruned(c->stream, LP, G, rows, rpl));
-    c->fault_armed = true;
     *taken = 1;
     return bracket_close(c, stop);
 }
@@ -3722,7 +3728,7 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             A.nconst = nconst; A.cconst = cconst;
             A.logx = logxs;
             int taken = 0;
-            if (profile_fft_pruned(c, A, rows, &taken)) return 1;
+            if (profile_fft_pruned(c, A, rows, FP != nullptr, &taken)) return 1;
             if (taken) return 0;
         }
         if (FP) {
@@ -3748,10 +3754,10 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             const FftPlanDev& pl = FP->plan;
             const bool spec2500 = FUSED_NT == 512 && pl.M == 2500 && pl.npass == 5 && pl.radix[0] == 4 && pl.radix[1] == 5 &&
                                   pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
-                                  !getenv("HMG_FUSED_GENERIC");      // (testing: force the run-time plan)
+                                  !c->fused_generic;      // (testing: force the run-time plan)
             const bool grouped = C && nchain > 0 && FUSED_NT == 512;
             // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 4000
-            const int ctM = (FUSED_NT == 512 && !getenv("HMG_FUSED_GENERIC") &&
+            const int ctM = (FUSED_NT == 512 && !c->fused_generic &&
                              (pl.M == 500 || pl.M == 1000 || pl.M == 2000)) ? pl.M : 0;
             if (grouped) {
                 if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds);
@@ -3824,6 +3830,12 @@ int hmg_profile_fft(hmg_ctx* c, int nz, int nm, int nk, int nxs, double step, co
     const hmg_profile_fft_part p{nxs, step, xs, kts, amp, xcs, alpha, expo, amp_c, xc_c, alpha_c, expo_c, gamma,
                                  cmax, rss, zs, ks, do_mass_norm, post, out, nconst, cconst, logxs};
     return profile_fft_impl(c, nz, nm, nk, p, nullptr, 0, 0, nullptr);
+}
+
+int hmg_profile_support_epoch(hmg_ctx* c, long long epoch) {
+    REQUIRE(c, "NULL ctx");
+    c->support_epoch = epoch;
+    return 0;
 }
 
 int hmg_profile_fft_logx(hmg_ctx* c, int nxs, const double* xs, double* logxs) {

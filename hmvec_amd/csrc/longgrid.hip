@@ -94,7 +94,7 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     if (!(A.xs[2 * LP] > cm)) {                    // (2 LP < nxs: R >= 2; xs increasing)
         for (int i = threadIdx.x; i < A.nk; i += NT) dst[i] = __builtin_nan("");
         if (threadIdx.x == 0) {
-            atomicOr(G.fault, 1);
+            __hip_atomic_store(G.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (A.nconst) { A.nconst[row] = 0; A.cconst[row] = __builtin_nan(""); }
         }
         return;
@@ -467,7 +467,7 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
     if (2 * jn + 2 > LB || 2 * jn + 1 > MAXA * NT) {
         for (int i = threadIdx.x; i < A.nk; i += NT) dst[i] = __builtin_nan("");
         if (threadIdx.x == 0) {
-            atomicOr(G.fault, 1);
+            __hip_atomic_store(G.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (A.nconst) { A.nconst[row] = 0; A.cconst[row] = __builtin_nan(""); }
         }
         return;

@@ -11,6 +11,7 @@ those return numpy arrays (copied from the device on first access, then cached);
 assigning a numpy array to ``uk_profiles[name]`` uploads it.
 """
 import ctypes as C
+import itertools
 import os
 from collections.abc import MutableMapping
 
@@ -26,6 +27,7 @@ from .functions import context as fn_context
 from .utils import vectorized_bisection_search
 
 _trapz = getattr(np, "trapezoid", None) or np.trapz
+_EPOCHS = itertools.count(1)      # content tags of the per-model (z,m) arrays (hmg_profile_support_epoch)
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
@@ -384,8 +386,10 @@ class HaloModel(Cosmology):
                              C.byref(prep) if prep is not None else None)
                 ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), None, None)
                 return prep is not None
+            ctx.call_now("hmg_profile_support_epoch", getattr(self, "_epoch", 0))
             ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), ref("hod") if hod_sums else None,
                          C.byref(prep) if prep is not None else None)
+            ctx.call_now("hmg_profile_support_epoch", 0)
             if nfw_alone is not None and "nfw_lane" in x:
                 ctx.call_now("hmg_event_wait", 7)
             return prep is not None
@@ -421,6 +425,11 @@ class HaloModel(Cosmology):
             self._release_inputs([k for k in self._dcache if k != "zs" and k != "ks" and k != "Pzk"
                                   and not (isinstance(k, tuple) and k[0] == "fftgrid")])
             self._ms_key = ms.copy()
+            # concentrations, radii and with them the support of every profile row and the modes it needs are
+            # functions of (cosmology, zs, ks, ms): fixed per model until the mass grid changes.  The tag lets the
+            # long-grid profile routes reuse the bound they measured once (hmg_profile_support_epoch) instead of
+            # synchronising the stream in every call.
+            self._epoch = next(_EPOCHS)
         self.ms = ms
         self._bump()
         if self.mode not in ("sheth-torman", "tinker"):
@@ -592,7 +601,9 @@ class HaloModel(Cosmology):
         if self._groups:
             self._queue("fft", nat.ProfileFftPart(*args))
         else:
+            ctx.call("hmg_profile_support_epoch", getattr(self, "_epoch", 0))
             ctx.call("hmg_profile_fft", nz, nm, nk, *args)
+            ctx.call("hmg_profile_support_epoch", 0)
         return out, hint
 
     def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref):

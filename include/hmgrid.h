@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMG_ABI_VERSION 6
+#define HMG_ABI_VERSION 7
 
 typedef struct hmg_ctx hmg_ctx;
 
@@ -244,15 +244,19 @@ int hmg_profile_rows_from_mvir(hmg_ctx* ctx, int kind, int nz, int nm, const dou
  *
  * Routes (chosen by the library from the radial grid and the rows' support; same results to <= 1e-12 in u):
  *   nxs = 1000, 2000, 4000, 5000      one (z,m) row per workgroup, packed-real FFT in LDS, compile-time plan;
- *   other even nxs <= 5000 whose half factors into 2, 3, 4, 5: the same with a run-time plan;
+ *   other even nxs <= 12288 (M = nxs/2 <= HMG_FUSED_MAX_M = 6144) whose half factors into 2, 3, 4, 5 with at most four
+ *     butterflies per thread in every pass: the same with a run-time plan - for M > 2500 (HMG_FUSED_PREFER_M) only
+ *     when the long-grid routes below do not apply (they are tried first there);
  *   longer grids - the ones the reference's own callers use: add_battaglia_profile(xmax=50, nxs=30000)
  *     (examples/lensing_baryons.py:27, bin/tests.py:308), numeric NFW nxs=40000 / xmax=200 (hmvec/params.py:59-60) -
  *     whose half is a multiple of a compiled sub-transform length LP >= the rows' support (profiles are cut at
  *     cmax << xmax): the long-grid kernels (R = nxs/2/LP pairs of length-LP transforms in LDS, or the chirp transform
  *     for rows that need few modes).  An EAGER call measures the support bound of its rows (one small kernel, a
- *     4-byte copy, one stream synchronisation); inside a captured step the bound of the last eager call on the same
- *     arrays is used and every row re-checks itself: a row beyond the bound is filled with NaN and the next
- *     synchronising call (hmg_sync, hmg_memcpy_d2h) returns an error;
+ *     4-byte copy, one stream synchronisation) unless hmg_profile_support_epoch has tagged the arrays' contents;
+ *     inside a captured step the bound on file for the same arrays is used (none on file: the one-row route if the
+ *     length has one, else an error) and every row re-checks itself: a row beyond the bound is filled with NaN and
+ *     the next synchronising call (hmg_sync, hmg_memcpy_d2h, hmg_event_synchronize) returns an error.  The tables of
+ *     these routes do not depend on HMG_FUSED_MAX_M;
  *   long grids whose support does NOT prune but whose rows all need few modes (2 jn + 2 <= 1000..1250; the tSZ notebook's
  *     add_battaglia_pres_profile(xmax=2, nxs=30000)): the narrow-band kernel - nxs/2/LB transforms of length LB of the
  *     decimated row, one accumulator per needed mode; needs the hint arrays (ascending d_ks); the bound on the needed
@@ -271,6 +275,15 @@ int hmg_profile_fft(hmg_ctx* ctx, int nz, int nm, int nk, int nxs, double fft_st
                     double* d_out /*[nz][nm][nk]*/,
                     int* d_nconst /*[nz][nm] or NULL*/, double* d_cconst /*[nz][nm] or NULL*/,
                     const double* d_logxs /*[nxs] from hmg_profile_fft_logx for the SAME d_xs, or NULL*/);
+/* Tag of the CONTENTS of the d_cmax / d_rss / d_zs / d_ks arrays the following profile calls of this context will be
+ * given (0, the default: no tag).  The long-grid routes size their launches from a bound on the rows' support and on
+ * the modes they need; an untagged eager call measures that bound every time (a stream synchronisation).  With a
+ * non-zero tag the bound measured by the first call with the same arrays, sizes and tag is reused - no host
+ * synchronisation in later calls - on the caller's promise that equal tags mean equal contents.  A promise that
+ * does not hold is caught, not computed through: every row re-checks itself, a row beyond the bound is filled with
+ * NaN and the next synchronising call (hmg_sync, hmg_memcpy_d2h, hmg_event_synchronize) fails and drops the cached
+ * bounds.  (The facade tags per model and mass grid: a model's concentrations and radii do not change.)          */
+int hmg_profile_support_epoch(hmg_ctx* ctx, long long epoch);
 /* ln xs[n]: the same for every (z,m) row, so a caller whose x grid does not change between passes
  * computes it once and hands it to hmg_profile_fft (one transcendental fewer per sample; without it
  * the kernel evaluates the logarithm itself, or builds the table per call when there are many rows). */
