@@ -28,6 +28,7 @@ import os
 import subprocess
 import sys
 import time
+import uuid
 
 import numpy as np
 
@@ -39,7 +40,8 @@ PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"),
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_CYCLES = 4      # a wave64 fp64 VALU instruction occupies its SIMD-32 for 4 cycles
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-PROFILE_DIR = os.path.join(REPO, "profiles", "r04")
+PROFILE_ROUND = "r05"
+PROFILE_DIR = os.path.join(REPO, "profiles", PROFILE_ROUND)
 BRACKET_EVERY = int(os.environ.get("HMG_BENCH_BRACKET_EVERY", "8"))   # kernel-level HIP events ride on every 8th timed step
 
 
@@ -71,16 +73,18 @@ def spawn_ranks(args, argv, cmd=None):
         cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run"]
     deadline_s = float(os.environ.get("HMG_LAUNCH_DEADLINE", "540"))      # under the driver's 600 s
     envs = []
+    launch_nonce = uuid.uuid4().hex      # one per launch: tells this launch's rendezvous file from a leftover of the same name
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HMG_LAUNCH_TAG=f"{port}_{os.getpid()}")
+                   MASTER_PORT=str(port), HMG_LAUNCH_TAG=f"{port}_{os.getpid()}",
+                   HMG_LAUNCH_NONCE=launch_nonce)
         # dmabuf IPC is the only mode the host driver of this pool supports; RCCL's peer set-up needs it
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # a supervised rank never needs to wait for the id longer than the slowest first library page-in
         env.setdefault("HMG_RDZV_TIMEOUT", "240")
         envs.append(env)
     if args.dry_run:
-        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HMG_LAUNCH_TAG",
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HMG_LAUNCH_TAG", "HMG_LAUNCH_NONCE",
                 "HSA_ENABLE_IPC_MODE_LEGACY", "HMG_RDZV_TIMEOUT")
         print(json.dumps({"dry_run": True, "n_ranks": n, "cmd": cmd, "deadline_s": deadline_s,
                           "rank_env": [{k: e[k] for k in keys} for e in envs]}))
@@ -578,7 +582,10 @@ def main():
     def _read_brackets():
         for k in BR:
             if not (k == "power" and args.per_pair):
-                kern_ms[k].append(ctx.elapsed_ms(*EV_BR[k]))
+                try:
+                    kern_ms[k].append(ctx.elapsed_ms(*EV_BR[k]))
+                except nat.NativeError:      # a stage that rode in another stage's launch leaves its bracket unrecorded
+                    pass
         if args.stages:
             stage_ms.append([ctx.elapsed_ms(EV_STAGE + j, EV_STAGE + j + 1) for j in range(5)])
 
@@ -629,7 +636,7 @@ def main():
         return
 
     # ---- bytes: the implementation's own model and, for the default configuration,
-    # the PMC counters of profiles/r04 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+    # the PMC counters of profiles/<round> (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
     default_cfg = ((args.nz, args.nm, args.nk, args.nxs, args.xmax) == (32, 512, 4096, 5000, 20.0) and world == 1
                    and not args.per_pair)
     sha = nat.kernel_source_sha16()
@@ -683,7 +690,7 @@ def main():
         ms_ = kms[key]
         moved = pmc_bytes(sub) or model[key]
         e = {"bound": bound, "ms": ms_, "bytes_moved": moved,
-             "bytes_source": "pmc (profiles/r04/pmc_traffic.json)" if pmc_bytes(sub) else "model (DESIGN.md section 4)",
+             "bytes_source": f"pmc (profiles/{PROFILE_ROUND}/pmc_traffic.json)" if pmc_bytes(sub) else "model (DESIGN.md section 4)",
              "bytes_model": model[key], "hbm_GBps": moved / (ms_ * 1e-3) / 1e9 if ms_ else None,
              "hbm_frac": moved / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ else None,
              "survey_alg_bytes": alg[key], "note": note}
@@ -859,15 +866,17 @@ def main():
         "roofline": {"kernel": "hmg::power_batch_kernel" if not args.per_pair else "hmg::power_kernel x6 (per-pair path)",
                      "bound": "hbm", "achieved": pw["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": pw["hbm_frac"], "traffic": pmc_bytes("power_batch_kernel"),
-                     "traffic_source": ("stored profile profiles/r04/pmc_traffic.json of this build: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                     "traffic_source": (f"stored profile profiles/{PROFILE_ROUND}/pmc_traffic.json of this build: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                         "separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch "
                                         "(gfx950 FETCH_SIZE correction)") if pmc else None,
                      "bytes_moved": pw["bytes_moved"], "bytes_source": pw["bytes_source"], "bytes_model": pw["bytes_model"],
                      "ms_per_launch": kms["power"],
                      "alg_bytes_per_launch": alg["power"],
                      "alg_equiv_GBps": alg["power"] / (kms["power"] * 1e-3) / 1e9 if kms["power"] else None,
-                     "note": "this block is the dominant HBM-BOUND kernel; the kernel the step spends most TIME in is fp64-VALU/LDS "
-                             "bound and has its own block, roofline_time_dominant.  achieved/frac use the bytes the launch actually moves (counter bytes when a profile of this "
+                     "note": f"HBM-bound kernel ({100 * (kms['power'] or 0.0) / (dt_max / K * 1e3):.0f} % of the step); time-dominant: "
+                             f"{roofline_time_dominant['kernel']} ({100 * roofline_time_dominant['share_of_step']:.0f} % of the step, "
+                             f"{roofline_time_dominant['bound']}, VALU issue frac {roofline_time_dominant['valu_issue_frac']}) "
+                             "- its block is roofline_time_dominant.  achieved/frac use the bytes the launch actually moves (counter bytes when a profile of this "
                              "configuration is stored, else the launch's own skip rule evaluated on the hint array); "
                              "alg_equiv_GBps prices the SURVEY 8d algorithmic bytes, of which the hinted constant prefix "
                              "is never read"},

@@ -125,6 +125,7 @@ struct hmg_ctx {
     int use_chirp = 1;                             // HMG_CHIRP=0: every row of a long grid takes the decomposition
     int use_band_fft = 1;                          // HMG_BAND_FFT=0: supports that do not prune go to rocFFT
     int fused_generic = 0;                         // HMG_FUSED_GENERIC=1 (testing): the run-time plan for every one-row length
+    int force_gatherv = 0;                         // HMG_FORCE_GATHERV=1 (testing): no all-gather shortcut for equal slab lengths
     std::map<std::tuple<int, int, int>, ChirpPlan> chirp;   // (nxs, LP, p0) -> tables
     std::map<std::pair<int, int>, PrunedPlan> pruned;   // (nxs, LP) -> tables of the long-grid routes
     std::map<int, hmg::cplx*> pass_tw;             // L -> per-pass twiddle table of the length-L plan (ldsfft.hpp)
@@ -2754,6 +2755,7 @@ static int ctx_init(hmg_ctx* c, int device) {
     if (const char* s = getenv("HMG_CHIRP")) c->use_chirp = atoi(s);
     if (const char* s = getenv("HMG_BAND_FFT")) c->use_band_fft = atoi(s);
     if (getenv("HMG_FUSED_GENERIC")) c->fused_generic = 1;
+    if (const char* s = getenv("HMG_FORCE_GATHERV")) c->force_gatherv = atoi(s);
     HIP_TRY(hipHostMalloc((void**)&c->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent));
     *c->h_fault = 0;
     HIP_TRY(hipHostGetDevicePointer((void**)&c->d_fault, c->h_fault, 0));
@@ -3408,6 +3410,8 @@ static int get_plan(hmg_ctx* c, int nxs, int batch, FftPlan** out) {
     auto key = std::make_pair(nxs, batch);
     auto it = c->plans.find(key);
     if (it != c->plans.end()) { *out = &it->second; return 0; }
+    // (plan creation compiles kernels at run time and allocates the work buffer: nothing a captured step may contain)
+    REQUIRE(!c->capturing, "a rocFFT plan cannot be created inside a captured step: run the step once eagerly first");
     FftPlan P;
     size_t len = (size_t)nxs;
     FFT_TRY(rocfft_plan_create(&P.plan, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -4538,7 +4542,9 @@ static int comm_gatherv_multi(hmg_ctx* c, int n, const double* const* send, doub
     const int nr = c->comm ? c->comm_size : 1, me = c->comm ? c->comm_rank : 0;
     bool equal = true;
     for (int r = 1; r < nr; ++r) equal = equal && counts[r] == counts[0];
-    if (equal) return hmg_comm_allgather_multi(c, n, send, recv, counts[0]);
+    // (HMG_FORCE_GATHERV=1, testing: equal counts take the per-rank branch too, so that a one-rank communicator on a
+    // one-GPU box runs the grouped broadcasts - root out of place - that only unequal slabs on several GPUs reach)
+    if (equal && !(c->force_gatherv && c->comm)) return hmg_comm_allgather_multi(c, n, send, recv, counts[0]);
     NCCL_TRY(ncclGroupStart());
     for (int i = 0; i < n; ++i) {
         size_t off = 0;

@@ -69,14 +69,56 @@ def _launch_name():
     return run_id if run_id not in ("", "none") else None
 
 
+def _launch_salt():
+    """Something only THIS launch has, for launches that carry a name: the name alone (a fixed --rdzv-id in a job
+    script, a fixed HMG_LAUNCH_TAG) is shared with a crashed earlier launch of the same job, whose rendezvous file
+    would then carry the same nonce.  HMG_LAUNCH_NONCE (bench.py's launcher exports a fresh one per launch), else the
+    per-launch directory torchrun creates for its error files (TORCHELASTIC_ERROR_FILE =
+    <log dir>/<run id>_<random>/attempt_<n>/<rank>/error.json: two levels up is common to the ranks of an attempt
+    and random per launch).  Empty when the launcher offers neither: see _stale()."""
+    salt = os.environ.get("HMG_LAUNCH_NONCE")
+    if salt:
+        return salt
+    ef = os.environ.get("TORCHELASTIC_ERROR_FILE")
+    if ef:
+        return os.path.dirname(os.path.dirname(ef))
+    return ""
+
+
+def _parent_start_wall():
+    """Wall-clock start of the parent process (boot time + start ticks), or None."""
+    try:
+        with open("/proc/stat", "rb") as f:
+            btime = next(int(l.split()[1]) for l in f if l.startswith(b"btime"))
+        return btime + int(_parent_start_ticks()) / os.sysconf("SC_CLK_TCK")
+    except (OSError, StopIteration, ValueError):
+        return None
+
+
+def _stale(path):
+    """A NAMED launch without a per-launch salt cannot tell its own file from the leftover of a crashed launch of the
+    same name by content.  Its readers then ignore a file written before their parent process started (two seconds of
+    slack for clock granularity): a leftover predates the whole launch, while rank 0 of this launch writes after the
+    launcher - every rank's parent or an ancestor of it - has started.  (A per-rank wrapper that starts AFTER rank 0
+    has already published would wait out its time limit: launchers that wrap ranks should export HMG_LAUNCH_NONCE.)"""
+    if not _launch_name() or _launch_salt():
+        return False
+    t0 = _parent_start_wall()
+    try:
+        return t0 is not None and os.stat(path).st_mtime < t0 - 2.0
+    except OSError:
+        return False
+
+
 def launch_identity(tag, world):
     """Text that every rank of THIS launch knows and no earlier launch could have written.  A launcher that
     names the launch says so: HMG_LAUNCH_TAG, or torchrun's TORCHELASTIC_RUN_ID (with the restart count) - these
     hold whatever sits between the launcher and the ranks (a per-rank wrapper script gives every rank a different
-    parent).  Only when neither is set does the identity fall back on the parent process: its PID and start time."""
+    parent) - together with the launch's salt (_launch_salt), since a name can be the same from launch to launch.
+    Only when neither is set does the identity fall back on the parent process: its PID and start time."""
     restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
     named = _launch_name()
-    who = f"id:{named}" if named else f"pp{os.getppid()}@{_parent_start_ticks()}"
+    who = f"id:{named}+{_launch_salt()}" if named else f"pp{os.getppid()}@{_parent_start_ticks()}"
     return f"{tag}|w{world}|{who}|r{restart}"
 
 
@@ -123,7 +165,7 @@ def exchange_unique_id(ctx, rank, world, tag):
             with open(path, "rb") as f:
                 raw = f.read()
             if len(raw) == NONCE_BYTES + nat.COMM_ID_BYTES:
-                if raw[:NONCE_BYTES] == nonce:
+                if raw[:NONCE_BYTES] == nonce and not _stale(path):
                     buf.raw = raw[NONCE_BYTES:]
                     return buf
                 seen = raw[:NONCE_BYTES]

@@ -371,13 +371,8 @@ class HaloModel(Cosmology):
         if any(k in st for k in ("massfn", "rows", "nfw")):
             ctx.call_now("hmg_group_rows", nz, nm, nk, nq, ref("massfn"), None, ref("rows"), ref("nfw"))
         if nfw_alone is not None:
-            side = "nfw_lane" in x       # experiment: the NFW rows on a second stream beside the profile rows
-            if side:
-                ctx.call_now("hmg_event_record", 6); ctx.call_now("hmg_lane_set", 2); ctx.call_now("hmg_event_wait", 6)
             ctx.call_now("hmg_nfw_analytic", nz, nm, nk, nfw_alone.d_cs, nfw_alone.d_rs, nfw_alone.d_zs, nfw_alone.d_ks,
                          nfw_alone.d_nfw_series, nfw_alone.d_uk)
-            if side:
-                ctx.call_now("hmg_event_record", 7); ctx.call_now("hmg_lane_set", 0)
         if "fft" in st or hod_sums:
             if "chain_alone" in x and "fft" in st and (hod_sums or prep is not None):
                 # experiment: the per-z chain as a launch of its own in front of the stand-alone
@@ -390,11 +385,7 @@ class HaloModel(Cosmology):
             ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), ref("hod") if hod_sums else None,
                          C.byref(prep) if prep is not None else None)
             ctx.call_now("hmg_profile_support_epoch", 0)
-            if nfw_alone is not None and "nfw_lane" in x:
-                ctx.call_now("hmg_event_wait", 7)
             return prep is not None
-        if nfw_alone is not None and "nfw_lane" in x:
-            ctx.call_now("hmg_event_wait", 7)
         return False
 
     # ------------------------------------------------------------------ mass function

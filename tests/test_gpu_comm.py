@@ -39,6 +39,40 @@ def test_single_rank_communicator_roundtrip(tmp_path, monkeypatch):
     ctx.close()
 
 
+def test_per_rank_count_gather_runs_its_broadcast_branch_on_one_rank(tmp_path, monkeypatch):
+    """The unequal-slab gather (one grouped ncclBroadcast per array and rank) only runs when slab lengths differ, i.e.
+    on several GPUs.  HMG_FORCE_GATHERV=1 switches the equal-count shortcut off, so that a one-rank communicator on the
+    one-GPU box executes that branch on hardware - RCCL group launch, root out of place, asynchronous entry point on the
+    communication lane included - and the bytes are checked.  (Offsets beyond the first rank still need a second device:
+    the two-rank test below.)"""
+    import ctypes as C
+    from hmvec_amd import _native as nat
+    from hmvec_amd.dist import RcclComm
+    monkeypatch.setenv("HMG_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("HMG_FORCE_GATHERV", "1")
+    ctx = nat.Context(0)
+    comm = RcclComm(ctx, 0, 1, f"testv_{os.getpid()}", force_init=True)
+    rng = np.random.default_rng(2)
+    a = [rng.standard_normal((5, 33)) for _ in range(6)]
+    sends = [ctx.upload(x) for x in a]
+    sp = (C.c_void_p * 6)(*[s.ptr for s in sends])
+    r1 = [ctx.empty((5, 33)) for _ in a]
+    ctx.call("hmg_comm_allgatherv_multi", 6, sp, (C.c_void_p * 6)(*[r.ptr for r in r1]), (C.c_size_t * 1)(165))
+    for x, r in zip(a, r1):
+        assert np.array_equal(r.numpy(), x)
+    r2 = [ctx.empty((5, 33)) for _ in a]
+    ctx.call("hmg_comm_gatherv_async", 6, sp, (C.c_void_p * 6)(*[r.ptr for r in r2]), (C.c_size_t * 1)(165), 8, 9, 3)
+    ctx.wait(9)
+    for x, r in zip(a, r2):
+        assert np.array_equal(r.numpy(), x)
+    # in place (send == recv): the root's own block stays where it is
+    ctx.call("hmg_comm_allgatherv_multi", 6, sp, sp, (C.c_size_t * 1)(165))
+    for x, s_ in zip(a, sends):
+        assert np.array_equal(s_.numpy(), x)
+    comm.close()
+    ctx.close()
+
+
 def test_gather_overlaps_on_its_own_lane_and_stays_ordered(tmp_path, monkeypatch):
     """ShardedSpectra issues the all-gather on the communication lane behind an event so that the next
     pass overlaps it.  With a 1-rank communicator the gather is a copy, which is enough to check the

@@ -124,3 +124,67 @@ def test_launch_identity_survives_wrappers_and_long_tags(monkeypatch):
     assert f"pp{os.getppid()}" in dist.launch_identity("29500_x", 2)
     monkeypatch.setenv("HMG_LAUNCH_TAG", "mine")                    # the explicit tag wins
     assert "id:mine" in dist.launch_identity("29500_x", 2)
+
+
+def test_a_named_launch_rejects_the_leftover_of_an_earlier_launch_with_the_same_name(tmp_path, monkeypatch):
+    """a launch that carries a name (HMG_LAUNCH_TAG, a fixed --rdzv-id) shares that name - file path and,
+    without more, nonce - with a crashed earlier launch of the same job.  (a) With a per-launch salt (HMG_LAUNCH_NONCE
+    from bench.py's launcher, or torchrun's per-launch error-file directory) the nonces differ: the leftover is
+    rejected by content.  (b) Without one the readers ignore a file written before their parent process started."""
+    import ctypes
+    import threading
+    import time
+    from hmvec_amd import _native as nat
+    from hmvec_amd import dist
+
+    monkeypatch.setenv("HMG_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("HMG_LAUNCH_TAG", "nightly-job")
+    monkeypatch.delenv("TORCHELASTIC_ERROR_FILE", raising=False)
+
+    class StubLib:
+        @staticmethod
+        def hmg_comm_unique_id(buf):
+            ctypes.memmove(buf, bytes(range(128)), 128)
+            return 0
+
+    class StubCtx:
+        lib = StubLib()
+
+    tag = "29500_fixed"
+    path = dist.rendezvous_path(tag, 2)
+
+    def leftover(nonce):
+        with open(path, "wb") as f:
+            f.write(nonce + b"\xee" * nat.COMM_ID_BYTES)
+
+    def read_with(expect_wait):
+        got = {}
+        t = threading.Thread(target=lambda: got.update(id=dist.exchange_unique_id(StubCtx(), 1, 2, tag).raw))
+        t.start()
+        time.sleep(0.2)
+        assert ("id" not in got) == expect_wait
+        uid = dist.exchange_unique_id(StubCtx(), 0, 2, tag)
+        t.join(timeout=10)
+        assert got["id"] == uid.raw == bytes(range(128))
+
+    # (a) the earlier launch had another salt
+    monkeypatch.setenv("HMG_LAUNCH_NONCE", "launch-1")
+    old = dist.launch_nonce(tag, 2)
+    monkeypatch.setenv("HMG_LAUNCH_NONCE", "launch-2")
+    assert dist.launch_nonce(tag, 2) != old
+    leftover(old)
+    read_with(expect_wait=True)
+    # torchrun's per-launch directory plays the same part
+    monkeypatch.delenv("HMG_LAUNCH_NONCE")
+    monkeypatch.setenv("TORCHELASTIC_ERROR_FILE", "/tmp/torchelastic_ab12/job_x1/attempt_0/1/error.json")
+    a = dist.launch_nonce(tag, 2)
+    monkeypatch.setenv("TORCHELASTIC_ERROR_FILE", "/tmp/torchelastic_ab12/job_x1/attempt_0/0/error.json")
+    assert dist.launch_nonce(tag, 2) == a                       # common to the ranks of an attempt
+    monkeypatch.setenv("TORCHELASTIC_ERROR_FILE", "/tmp/torchelastic_zz99/job_q7/attempt_0/0/error.json")
+    assert dist.launch_nonce(tag, 2) != a                       # another launch
+    # (b) no salt at all: same name, same nonce - the leftover is older than this process's parent
+    monkeypatch.delenv("TORCHELASTIC_ERROR_FILE")
+    leftover(dist.launch_nonce(tag, 2))
+    os.utime(path, (time.time() - 7 * 86400,) * 2)
+    assert dist._stale(path)
+    read_with(expect_wait=True)
