@@ -1163,7 +1163,9 @@ template <int MAXB, int SPECM> constexpr int fused_occ() { return MAXB > 2 ? 4 :
 #ifndef HMG_ABL
 #define HMG_ABL 0
 #endif
-template <int NT, int MAXB, int MAXP, int SPECM, int ABL = HMG_ABL>
+// TAB: the profile is read from a table (a user's callable evaluated on the x grid: hmvec/fft.py:56-94) instead of
+// evaluated from the family; everything behind the integrand is the same code.
+template <int NT, int MAXB, int MAXP, int SPECM, int ABL = HMG_ABL, bool TAB = false>
 __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, double* smem) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
@@ -1182,7 +1184,8 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     const double EX = A.expo ? A.expo[row] : A.expo_c;
     const double cm = A.cmax[row];
     // ln(x/xc) = ln x - ln xc: ln x is row-independent (xc == 1 for the gas and NFW members: no logarithm)
-    const double ln_xc = (A.xc == nullptr && A.xc_c == 1.0) ? 0.0 : log_fast(XC);
+    const double ln_xc = (TAB || (A.xc == nullptr && A.xc_c == 1.0)) ? 0.0 : log_fast(XC);
+    const double* __restrict__ tab = TAB ? A.rho_tab + (A.rho_shared ? (size_t)0 : (size_t)row * (size_t)(SPECM ? 2 * SPECM : A.nxs)) : nullptr;
     // Output side of the row: the FFT modes sit on the uniform grid kout_j = j k_lo,
     // k_lo = kt_1 / (r_s (1+z)).  Targets below k_lo take np.interp's left fill u_1, targets above
     // kout_M are zero, and only the modes j <= jn = floor(max(ks)/k_lo) + 2 can be reached at all:
@@ -1258,6 +1261,9 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         if constexpr (ABL == 4) {     // timing experiment: phase A without its transcendentals
             if (!(fabs(xv.x) > cm)) r0 = Aamp * xv.x + AL;
             if (!(fabs(xv.y) > cm)) r1 = Aamp * xv.y + EX;
+        } else if constexpr (TAB) {
+            if (!(fabs(xv.x) > cm)) r0 = tab[j];
+            if (!(fabs(xv.y) > cm)) r1 = tab[j + 1];
         } else {
             if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
             if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
@@ -1431,6 +1437,11 @@ template <int NT, int MAXB, int MAXP, int SPECM>
 __global__ __launch_bounds__(NT, (fused_occ<MAXB, SPECM>())) void profile_fused_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     profile_fused_row<NT, MAXB, MAXP, SPECM>(A, blockIdx.x, smem);
+}
+template <int NT, int MAXB, int MAXP, int SPECM>
+__global__ __launch_bounds__(NT, (fused_occ<MAXB, SPECM>())) void profile_table_kernel(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    profile_fused_row<NT, MAXB, MAXP, SPECM, HMG_ABL, true>(A, blockIdx.x, smem);
 }
 
 // (K45p, the long radial grids with short support - profile_pruned_kernel and the chirp route: longgrid.hip, a
@@ -3490,6 +3501,17 @@ static int launch_fused(hmg_ctx* c, const FusedArgs& A, int rows) {
     return 0;
 }
 
+template <int MAXB, int MAXP, int SPECM = 0>
+static int launch_table(hmg_ctx* c, const FusedArgs& A, int rows) {
+    const size_t lds = (size_t)A.plan.M * 16 + 32 * sizeof(double);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)profile_table_kernel<FUSED_NT, MAXB, MAXP, SPECM>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((profile_table_kernel<FUSED_NT, MAXB, MAXP, SPECM>), dim3(rows), dim3(FUSED_NT), lds, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // profile_group_kernel = the fused row kernel with `nchain` per-z chain workgroups in front of the rows
 template <int MAXB, int MAXP, int SPECM = 0>
 static int launch_fused_group(hmg_ctx* c, const FusedArgs& A, int rows, const ChainArgs& C, int nchain, size_t chain_lds) {
@@ -3694,8 +3716,11 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, bool ca
 
 // One hmg_profile_fft; with a chain (nchain > 0) and a length the in-LDS transform takes, chain and rows share
 // the launch, otherwise *chain_done stays 0 and the caller issues the chain on its own.
+// rho_tab != nullptr: the profile comes from a table (hmg_profile_fft_table); *taken = 0 when no in-LDS route takes the
+// launch (the caller then runs its rocFFT chain); the family parameters of p are not read.
 static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part& p, const ChainArgs* C,
-                            int nchain, size_t chain_lds, int* chain_done) {
+                            int nchain, size_t chain_lds, int* chain_done, const double* rho_tab = nullptr,
+                            int rho_shared = 0, int* taken = nullptr) {
     const int nxs = p.nxs;
     const double step = p.fft_step;
     const double *xs = p.d_xs, *kts = p.d_kts, *amp = p.d_amp, *xcs = p.d_xc, *alpha = p.d_alpha, *expo = p.d_expo;
@@ -3731,9 +3756,13 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             A.step = step; A.cmax = cmax; A.rss = rss; A.zs = zs; A.ks = ks; A.post = post; A.out = out;
             A.nconst = nconst; A.cconst = cconst;
             A.logx = logxs;
-            int taken = 0;
-            if (profile_fft_pruned(c, A, rows, FP != nullptr, &taken)) return 1;
-            if (taken) return 0;
+            A.rho_tab = rho_tab; A.rho_shared = rho_shared;
+            int took = 0;
+            if (profile_fft_pruned(c, A, rows, FP != nullptr, &took)) return 1;
+            if (took) {
+                if (taken) *taken = 1;
+                return 0;
+            }
         }
         if (FP) {
             FusedArgs A;
@@ -3744,8 +3773,18 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             A.step = step; A.cmax = cmax; A.rss = rss; A.zs = zs; A.ks = ks; A.post = post; A.out = out;
             A.nconst = nconst; A.cconst = cconst;
             A.logx = logxs;
+            A.rho_tab = rho_tab; A.rho_shared = rho_shared;
             int stop = -1;
             if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
+            if (rho_tab) {      // table builds: the nxs = 5000 plan and two run-time-plan shapes cover every one-row length
+                int rc;
+                if (FUSED_NT == 512 && FP->plan.M == 2500 && !c->fused_generic) rc = launch_table<2, 3, 2500>(c, A, rows);
+                else if (FP->maxb <= 2 && FP->maxp <= 4) rc = launch_table<2, 4>(c, A, rows);
+                else rc = launch_table<4, 8>(c, A, rows);
+                if (rc) return 1;
+                if (taken) *taken = 1;
+                return bracket_close(c, stop);
+            }
             if (!logxs && rows >= 8192) {   // no prepared table: its own launch pays from ~8000 rows (MI355X: -1 % at 16384 rows, +2 % at 4096)
                 if (ensure_scratch(c, 2, (size_t)nxs * 8)) return 1;
                 hipLaunchKernelGGL(logx_kernel, grid1d((size_t)nxs, 256), dim3(256), 0, c->stream, nxs, xs,
@@ -3760,14 +3799,17 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
                                   pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
                                   !c->fused_generic;      // (testing: force the run-time plan)
             const bool grouped = C && nchain > 0 && FUSED_NT == 512;
-            // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 4000
+            // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 3000, 4000, 6000 (the last one only
+            // when its rows' support does not let the long-grid route take it)
             const int ctM = (FUSED_NT == 512 && !c->fused_generic &&
-                             (pl.M == 500 || pl.M == 1000 || pl.M == 2000)) ? pl.M : 0;
+                             (pl.M == 500 || pl.M == 1000 || pl.M == 1500 || pl.M == 2000 || pl.M == 3000)) ? pl.M : 0;
             if (grouped) {
                 if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds);
                 else if (ctM == 500) rc = launch_fused_group<1, 1, 500>(c, A, rows, *C, nchain, chain_lds);
                 else if (ctM == 1000) rc = launch_fused_group<1, 1, 1000>(c, A, rows, *C, nchain, chain_lds);
+                else if (ctM == 1500) rc = launch_fused_group<1, 2, 1500>(c, A, rows, *C, nchain, chain_lds);
                 else if (ctM == 2000) rc = launch_fused_group<2, 2, 2000>(c, A, rows, *C, nchain, chain_lds);
+                else if (ctM == 3000) rc = launch_fused_group<3, 3, 3000>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 1 && mp <= 2) rc = launch_fused_group<1, 2>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 2 && mp <= 3) rc = launch_fused_group<2, 3>(c, A, rows, *C, nchain, chain_lds);
                 else if (mb <= 2 && mp <= 4) rc = launch_fused_group<2, 4>(c, A, rows, *C, nchain, chain_lds);
@@ -3777,7 +3819,9 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             else if (spec2500) rc = launch_fused<2, 3, 2500>(c, A, rows);                 // nxs = 5000, compile-time plan
             else if (ctM == 500) rc = launch_fused<1, 1, 500>(c, A, rows);
             else if (ctM == 1000) rc = launch_fused<1, 1, 1000>(c, A, rows);
+            else if (ctM == 1500) rc = launch_fused<1, 2, 1500>(c, A, rows);
             else if (ctM == 2000) rc = launch_fused<2, 2, 2000>(c, A, rows);
+            else if (ctM == 3000) rc = launch_fused<3, 3, 3000>(c, A, rows);
             else if (mb <= 1 && mp <= 2) rc = launch_fused<1, 2>(c, A, rows);
             else if (mb <= 2 && mp <= 3) rc = launch_fused<2, 3>(c, A, rows);
             else if (mb <= 2 && mp <= 4) rc = launch_fused<2, 4>(c, A, rows);
@@ -3785,6 +3829,10 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             if (rc) return 1;
             return bracket_close(c, stop);
         }
+    }
+    if (rho_tab) {              // no in-LDS route for this length: the caller's table -> rocFFT chain
+        if (taken) *taken = 0;
+        return 0;
     }
     // ---- rocFFT path.  Chunk the batch so integrand + spectrum of a chunk stay inside the 256 MiB Infinity Cache:
     // the R2C input written by K4 and the spectrum read by K5 then never round-trip through HBM.
@@ -4443,6 +4491,15 @@ int hmg_profile_fft_table(hmg_ctx* c, int nz, int nm, int nk, int nxs, double st
     REQUIRE(step > 0.0, "step must be positive");
     const int rows = nz * nm;
     REQUIRE(rho_rows == 1 || rho_rows == rows, "rho must have 1 or nz*nm rows");
+    {   // the in-LDS routes of hmg_profile_fft with the table in the place of the family's integrand
+        hmg_profile_fft_part p{};
+        p.nxs = nxs; p.fft_step = step; p.d_xs = xs; p.d_kts = kts; p.d_cmax = cmax; p.d_rss = rss; p.d_zs = zs; p.d_ks = ks;
+        p.do_mass_norm = do_mass_norm; p.d_out = out;
+        p.amp_const = p.xc_const = p.alpha_const = p.expo_const = 1.0;
+        int taken = 0;
+        if (profile_fft_impl(c, nz, nm, nk, p, nullptr, 0, 0, nullptr, rho, rho_rows == 1, &taken)) return 1;
+        if (taken) return 0;
+    }
     const int nh = nxs / 2;
     const size_t per_row = (size_t)nxs * 8 + (size_t)(nh + 1) * 16;
     size_t budget = c->fft_chunk_bytes ? c->fft_chunk_bytes : ((size_t)160 << 20);

@@ -133,6 +133,7 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         }
     }
     // ---- phase A: the LP packed samples that can be non-zero (into registers), and the mass norm
+    const double* __restrict__ tab = A.rho_tab ? A.rho_tab + (A.rho_shared ? (size_t)0 : (size_t)row * (size_t)nxs) : nullptr;
     cplx zp[MAXB0][R0];
     double acc = 0.0;
 #pragma unroll
@@ -149,8 +150,13 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                 if (!(fabs(xv.x) > cm)) r0 = Aamp * xv.x + AL;
                 if (!(fabs(xv.y) > cm)) r1 = Aamp * xv.y + EX;
 #else
-                if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
-                if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+                if (tab) {       // a user's profile from a table (hmg_profile_fft_table): wave-uniform
+                    if (!(fabs(xv.x) > cm)) r0 = tab[j];
+                    if (!(fabs(xv.y) > cm)) r1 = tab[j + 1];
+                } else {
+                    if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
+                    if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
+                }
 #endif
                 zp[b][t] = cplx{xv.x * r0, xv.y * r1};
                 if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {

@@ -54,6 +54,10 @@ struct FusedArgs {
     int* nconst;               // optional constant-prefix hint per row
     double* cconst;
     const double* logx;        // ln xs[n], shared by every row (nullptr: evaluated per sample)
+    // TAB builds of the row kernels (generic_profile_fft with a user's callable, hmvec/fft.py:56-94): the profile comes
+    // from a table instead of the family - rho_tab[n] shared by every row, or rho_tab[row nxs + n]
+    const double* rho_tab;
+    int rho_shared;
 };
 
 // amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two

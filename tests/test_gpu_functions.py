@@ -167,6 +167,51 @@ def test_generic_profile_fft_with_user_callables():
         hm.generic_profile_fft(lambda xx: xx[None, :] + 0 * cmax[:, :1], cmax, rss, Z, ks, 10.0, 64)
 
 
+@pytest.mark.parametrize("nxs,xmax", [(5000, 20.0), (3000, 20.0), (4000, 6.0), (30000, 50.0), (40000, 200.0)])
+def test_table_route_runs_the_row_kernels_of_the_builtin_families(nxs, xmax, monkeypatch):
+    """generic_profile_fft with a user's callable (hmvec/fft.py:56-94) takes the in-LDS row kernels too (round 5): the
+    table row stands where the family's integrand is evaluated, everything behind it is the same code.  (a) Bit
+    equality with the built-in route on a profile both evaluate to the same bits: gamma = 0, exponent 0, amplitude 1 is
+    the constant 1 exactly (exp(0) = 1), and so is a table of ones - one-row kernels (compile-time and run-time plans)
+    and the long-grid kernel (decomposition and chirp rows).  (b) A callable with structure against the table -> rocFFT
+    chain the route replaces (HMG_FUSED_FFT=0), to the 1e-12 gate on u."""
+    import ctypes as C
+    import hmvec_amd as hm
+    from hmvec_amd import _native as nat
+    nz, nm, nk = 2, 12, 150
+    xs = np.linspace(0.0, xmax, nxs + 1)[1:]
+    step = (xs[-1] - xs[0]) / nxs
+    kts = np.fft.rfftfreq(nxs, step) * 2 * np.pi
+    cmax = np.linspace(0.9, 2.9, nz * nm).reshape(nz, nm)
+    rss = np.geomspace(0.03, 2.5, nz * nm).reshape(nz, nm)
+    zs, ks = np.array([0.2, 1.7]), np.geomspace(1e-3, 80, nk)
+    ctx = nat.Context(0)
+    d_xs, d_kts, d_cmax, d_rss, d_zs, d_ks = (ctx.upload(a) for a in (xs, kts, cmax, rss, zs, ks))
+    out_f, out_t = ctx.empty((nz, nm, nk)), ctx.empty((nz, nm, nk))
+    ctx.call("hmg_profile_fft", nz, nm, nk, nxs, step, d_xs.ptr, d_kts.ptr, None, None, None, None,
+             1.0, 1.0, 1.0, 0.0, 0.0, d_cmax.ptr, d_rss.ptr, d_zs.ptr, d_ks.ptr, 1, None, out_f.ptr, None, None, None)
+    d_ones = ctx.upload(np.ones(nxs))
+    ctx.call("hmg_profile_fft_table", nz, nm, nk, nxs, step, d_xs.ptr, d_kts.ptr, d_ones.ptr, 1, d_cmax.ptr, d_rss.ptr,
+             d_zs.ptr, d_ks.ptr, 1, out_t.ptr)
+    a, b = out_f.numpy(), out_t.numpy()
+    assert np.all(np.isfinite(a)) and np.array_equal(a, b)
+    # per-row tables, a profile with structure
+    rho = (xs[None, None, :] / 0.7) ** -0.4 * (1.0 + (xs[None, None, :] / 0.7) ** (1.0 + 0.1 * np.arange(nz * nm).reshape(nz, nm, 1) / 24)) ** -2.5
+    d_rho = ctx.upload(rho.reshape(-1))
+    ctx.call("hmg_profile_fft_table", nz, nm, nk, nxs, step, d_xs.ptr, d_kts.ptr, d_rho.ptr, nz * nm, d_cmax.ptr, d_rss.ptr,
+             d_zs.ptr, d_ks.ptr, 1, out_t.ptr)
+    fused = out_t.numpy()
+    ctx.close()
+    monkeypatch.setenv("HMG_FUSED_FFT", "0")
+    ctx = nat.Context(0)
+    d_xs, d_kts, d_cmax, d_rss, d_zs, d_ks = (ctx.upload(a) for a in (xs, kts, cmax, rss, zs, ks))
+    d_rho, out_r = ctx.upload(rho.reshape(-1)), ctx.empty((nz, nm, nk))
+    ctx.call("hmg_profile_fft_table", nz, nm, nk, nxs, step, d_xs.ptr, d_kts.ptr, d_rho.ptr, nz * nm, d_cmax.ptr, d_rss.ptr,
+             d_zs.ptr, d_ks.ptr, 1, out_r.ptr)
+    assert np.max(np.abs(fused - out_r.numpy())) < 1e-12
+    ctx.close()
+
+
 def test_uk_fft():
     import hmvec_amd as hm
     k, u = hm.fft.uk_fft(lambda rr: 1.0 / (rr / 0.2) / (1.0 + rr / 0.2) ** 2, 1.5, dr=0.01, rmax=40)
