@@ -49,6 +49,52 @@ def get_eds_model(fb=0.15, H0=68.0, YHe=0.25):
     raise NotImplementedError("get_eds_model builds a CAMB parameter set (hmvec/cosmology.py:40-49); not on the path")
 
 
+_KGRIDS = {}
+
+
+def sigma2_kgrid(kmin, kmax, numks):
+    """The k' grid of the sigma^2 integral (hmvec/cosmology.py:245-250), one read-only array object per (kmin, kmax,
+    numks): models built on the same parameters share it, which is what lets Cosmology.Tk recognise the grid."""
+    key = (float(kmin), float(kmax), int(numks))
+    g = _KGRIDS.get(key)
+    if g is None:
+        if len(_KGRIDS) >= 8:
+            _KGRIDS.clear()
+        g = np.geomspace(kmin, kmax, numks)
+        g.setflags(write=False)
+        _KGRIDS[key] = g
+    return g
+
+
+_WQ = []
+
+
+def sigma2_weights(kq):
+    """Quadrature weights of the sigma^2 integral on the grid kq - simpson_weights(kq) kq^2 / (2 pi^2), hmvec/cosmology.py:
+    245-269 - kept per grid OBJECT (sigma2_kgrid hands out one per parameter set)."""
+    for g, w in _WQ:
+        if g is kq:
+            return w
+    w = simpson_weights(kq) * kq ** 2.0 / 2.0 / np.pi ** 2
+    w.setflags(write=False)
+    _WQ.insert(0, (kq, w))
+    del _WQ[8:]
+    return w
+
+
+_TK_CACHE = []          # (grid object, parameter key, grid stamp, T(k), scalars): Cosmology.Tk
+
+
+def _grid_stamp(ks):
+    """Cheap guard against a grid array that was modified in place after it was cached: its length, ends, middle and sum
+    of three more elements."""
+    if not isinstance(ks, np.ndarray) or ks.size == 0:
+        return None
+    n = ks.size
+    f = ks.reshape(-1)
+    return (n, float(f[0]), float(f[-1]), float(f[n // 2]), float(f[n // 3] + f[n // 5] + f[(2 * n) // 3]))
+
+
 class Cosmology(object):
     """``Cosmology(params, halofit, engine, accuracy)`` as in hmvec/cosmology.py:51-65.
 
@@ -166,7 +212,27 @@ class Cosmology(object):
 
     def Tk(self, ks, type="eisenhu_osc"):
         """Eisenstein & Hu 1998 transfer function (hmvec/cosmology.py:404-504).
-        Equation numbers refer to EH98; k in 1/Mpc on input, h/Mpc internally."""
+        Equation numbers refer to EH98; k in 1/Mpc on input, h/Mpc internally.
+
+        The value is a function of (omch2, ombh2, h, omm0) and the k grid only; a sweep builds model after model on
+        the same grids (the README sequence in a loop spends a quarter of its host time here), so the last few
+        results are kept - keyed by those numbers and by the grid OBJECT (an entry holds a reference to its grid, so
+        the identity test cannot be fooled by a recycled address; a caller that passes equal values in a new array
+        simply misses)."""
+        key = (type, float(self.h), float(self.params["omch2"]), float(self.params["ombh2"]), float(self.omm0))
+        for ent in _TK_CACHE:
+            if ent[0] is ks and ent[1] == key and ent[2] == _grid_stamp(ks):
+                (self.tcmb, self._k_eq, self._z_eq, self._z_d, self._R_d, self._R_eq, self.sh_d, self._k_silk) = ent[4]
+                return ent[3]
+        tk = self._Tk_eval(ks, type)
+        if isinstance(ks, np.ndarray):
+            tk.setflags(write=False)
+            _TK_CACHE.insert(0, (ks, key, _grid_stamp(ks), tk, (self.tcmb, self._k_eq, self._z_eq, self._z_d, self._R_d,
+                                                                 self._R_eq, self.sh_d, self._k_silk)))
+            del _TK_CACHE[8:]
+        return tk
+
+    def _Tk_eval(self, ks, type):
         h = self.h
         k = np.asarray(ks, dtype=np.float64) / h
         self.tcmb = 2.726
@@ -235,7 +301,7 @@ class Cosmology(object):
                 + self.get_Omega_nu() * self.params["H0"] ** 2.0)
         kfac = (ks / kp) ** (ns - 1.0) * ks
         pref = 8 * np.pi ** 2 * self.params["As"] / 25.0 / omh2 ** 2.0 * cspeed ** 4.0
-        return pref * kfac[None, :] * Dz ** 2.0 * tk ** 2.0
+        return pref * kfac[None, :] * Dz ** 2.0 * tk ** 2.0      # (the reference's order of products: same bits)
 
     # ------------------------------------------------------------------ Boltzmann-code P(k) (row N3)
     def get_pk_interpolator(self, zs, kmax, var="weyl", nonlinear=False, **kwargs):
@@ -303,7 +369,7 @@ class Cosmology(object):
         kmin = self.p["sigma2_kmin"] if kmin is None else kmin
         kmax = self.p["sigma2_kmax"] if kmax is None else kmax
         numks = self.p["sigma2_numks"] if numks is None else numks
-        ks_sigma2 = np.geomspace(kmin, kmax, numks)
+        ks_sigma2 = sigma2_kgrid(kmin, kmax, numks)
         if self.accuracy == "high":
             self.sPzk = self.P_lin_slow(ks_sigma2, zs, kmax=kmax)
         elif self.accuracy == "medium":

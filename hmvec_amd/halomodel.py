@@ -19,7 +19,7 @@ import numpy as np
 import scipy.constants as constants
 
 from . import _native as nat
-from .cosmology import Cosmology
+from .cosmology import Cosmology, sigma2_kgrid, sigma2_weights
 from .params import battaglia_defaults, default_params
 from .quadrature import gradient_is_uniform, simpson_weights, trapz_weights
 from .functions import FN_BG_INTEGRAND, FN_ST_FSIGMA, FN_TINKER_FSIGMA, fn2d, ngal_from_mthresh, trapz_lastaxis
@@ -433,14 +433,14 @@ class HaloModel(Cosmology):
         # sigma^2: inputs (P(k) on the sigma2 grid, Simpson weights, Lagrangian radii)
         if "sig_in" not in self._dcache:
             kmin, kmax, numks = self.p["sigma2_kmin"], self.p["sigma2_kmax"], self.p["sigma2_numks"]
-            kq = np.geomspace(kmin, kmax, numks)
+            kq = sigma2_kgrid(kmin, kmax, numks)
             if self.accuracy == "high":
                 self.sPzk = self.P_lin_slow(kq, self.zs, kmax=kmax)
             elif self.accuracy == "medium":
                 self.sPzk = self.P_lin(kq, self.zs)
             else:
                 self.sPzk = self.P_lin_approx(kq, self.zs)
-            wq = simpson_weights(kq) * kq ** 2.0 / 2.0 / np.pi ** 2
+            wq = sigma2_weights(kq)
             d_sP = ctx.upload(self.sPzk)
             # P(k',z) is an input of the path: lay it out once as the contraction reads it
             n = C.c_size_t()
@@ -1032,15 +1032,31 @@ class HaloModel(Cosmology):
         # summation order, ~1e-16 away) is left with what the batch cannot do: bias overrides, the verbose
         # terms, names the 1-halo and 2-halo lookups resolve differently, two different HOD/pressure names.
         if pairs and ((name, name2) in pairs or (name2, name) in pairs):
-            o1, o2 = self.power_device_batch(pairs)
-            for (a, b), d1, d2 in zip(pairs, o1, o2):
-                self._pcache[(a, b)] = (self._version, d1, d2)
-                self._pcache[(b, a)] = (self._version, d1, d2)
+            # every spectrum of the batch in ONE device block: the host side then fetches the block in one copy the
+            # first time any of them is asked for (_HostBlock) instead of one synchronising copy per spectrum
+            n = len(pairs)
+            blk = self._ctx().empty((2 * n, self._nz, self._nk))
+            per = self._nz * self._nk
+            o1 = [blk.view(i * per, (self._nz, self._nk)) for i in range(n)]
+            o2 = [blk.view((n + i) * per, (self._nz, self._nk)) for i in range(n)]
+            self.power_device_batch(pairs, outs1=o1, outs2=o2)
+            hb = _HostBlock(blk)
+            for i, ((a, b), d1, d2) in enumerate(zip(pairs, o1, o2)):
+                self._pcache[(a, b)] = (self._version, d1, d2, hb, i, n + i)
+                self._pcache[(b, a)] = (self._version, d1, d2, hb, i, n + i)
         else:
             d1, d2 = self.power_device(name, name2)
             self._pcache[(name, name2)] = (self._version, d1, d2)
         ent = self._pcache[(name, name2)]
         return ent[1], ent[2]
+
+    def _power_host(self, name, name2, term):
+        """Host copy of P_1h (term 0) or P_2h (term 1) of a cached pair."""
+        d = self._power_cached(name, name2)
+        ent = self._pcache[(name, name if name2 is None else name2)]
+        if len(ent) > 3:
+            return ent[3].take(ent[4 + term])
+        return d[term].numpy()
 
     def get_power(self, name, name2=None, verbose=False, b1=None, b2=None):
         """P_1h + P_2h in one pass (hmvec/hmvec.py:500-502)."""
@@ -1062,13 +1078,13 @@ class HaloModel(Cosmology):
 
     def get_power_1halo(self, name="nfw", name2=None):
         """hmvec/hmvec.py:504-526."""
-        return self._power_cached(name, name2)[0].numpy()
+        return self._power_host(name, name2, 0)
 
     def get_power_2halo(self, name="nfw", name2=None, verbose=False, b1_in=None, b2_in=None):
         """hmvec/hmvec.py:528-572."""
         self._tsz_notice(name, name if name2 is None else name2)
         if b1_in is None and b2_in is None:
-            out = self._power_cached(name, name2)[1].numpy()
+            out = self._power_host(name, name2, 1)
         else:
             out = self.power_device(name, name2, b1_in, b2_in, want=("2h",))[1].numpy()
         if verbose:
@@ -1093,6 +1109,24 @@ class HaloModel(Cosmology):
         i1, c1, i2, c2 = self.two_halo_terms(name, name2)
         print("Two-halo consistency1: ", c1, i1)
         print("Two-halo consistency2: ", c2, i2)
+
+
+class _HostBlock:
+    """The spectra of one batched launch on the host: fetched in one copy on first use.  Every array handed out is the
+    caller's own, as in the reference (a fresh array per call): a slice of the fetched block the first time a spectrum
+    is asked for, a new copy from the device after that (the first caller may have written into its slice)."""
+
+    def __init__(self, dev):
+        self.dev, self.host, self.given = dev, None, set()
+
+    def take(self, i):
+        if i in self.given:
+            n = self.dev.shape[1] * self.dev.shape[2]
+            return self.dev.view(i * n, self.dev.shape[1:]).numpy()
+        if self.host is None:
+            self.host = self.dev.numpy()
+        self.given.add(i)
+        return self.host[i]
 
 
 class SpectraBlock:
