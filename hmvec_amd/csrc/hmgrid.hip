@@ -3664,15 +3664,17 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, bool ca
         for (int lb : {1000, 1024, 1250})
             if (M % lb == 0 && band_lb_compiled(lb) && 2 * jnmax + 2 <= lb) { LB = lb; break; }
         if (!LB) return 0;
-        PrunedPlan* PP = nullptr;
+        PrunedPlan *PP = nullptr, *PR = nullptr;
         const cplx* twL = nullptr;
         if (get_pruned_plan(c, nxs, 0, &PP)) return 1;
+        if (get_pruned_plan(c, nxs, LB, &PR)) return 1;      // its twR: the mode twiddles W_M^(p1 j) by residue p1
         if (get_pass_table(c, LB, &twL)) return 1;
         PrunedArgs G{};
         G.F = A0;
         G.F.twN = PP->twN;
         if (ensure_scratch(c, 0, (size_t)3 * nxs * 8)) return 1;       // x, ln x, trapezoid weights in the kernel's walk order
         G.M = M; G.R = M / LB; G.twB = PP->twB; G.twL = twL; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
+        G.twR = PR->twR;
         int stop = -1;
         if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
         HIP_TRY((hipError_t)launch_band(c->stream, LB, G, rows, jnmax));

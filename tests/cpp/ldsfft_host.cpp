@@ -286,11 +286,9 @@ static int band_rfft_imag(const double* y, int n, int nthreads, int jn, double* 
     const std::vector<cplx> twL = pass_tw_table(S0::P);
     for (int t = 0; t < M; ++t) twB[t] = {(double)cosl(twopi * t / M), (double)-sinl(twopi * t / M)};
     const int nacc = 2 * jn + 1;
-    std::vector<cplx> acc(nacc, cplx{0.0, 0.0}), wcur(nacc, cplx{1.0, 0.0}), wstep(nacc);
-    for (int t = 0; t < nacc; ++t) {
-        const int j = band_mode(t, jn);
-        wstep[t] = twB[((j % M) + M) % M];
-    }
+    std::vector<cplx> acc(nacc, cplx{0.0, 0.0});
+    const std::vector<cplx> twR = residue_tw_table(M, LB);       // W_M^(p1 j) at [p1 LB + j], as the kernel reads it
+    (void)twB;
     constexpr int nb_last = SubPass<LB, S0::P.npass - 1>::nb;
     const int keep = (2 * jn + 2 < nb_last) ? jn : -1;
     for (int p1 = 0; p1 < D; ++p1) {
@@ -305,9 +303,11 @@ static int band_rfft_imag(const double* y, int n, int nthreads, int jn, double* 
         }
         run_single_passes<LB, 1>(buf, twL, keep, nthreads);
         for (int t = 0; t < nacc; ++t) {
-            const cplx yv = buf[band_index(band_mode(t, jn), LB)];
-            acc[t] = cadd(acc[t], cmul(yv, wcur[t]));
-            wcur[t] = cmul(wcur[t], wstep[t]);
+            const int j = band_mode(t, jn), ja = j < 0 ? -j : j;
+            const cplx yv = buf[band_index(j, LB)];
+            cplx w = twR[(size_t)p1 * LB + ja];
+            if (j < 0) w.y = -w.y;
+            acc[t] = cadd(acc[t], cmul(yv, w));
         }
     }
     for (int j = 0; j <= M; ++j) imF[j] = NAN;
