@@ -1165,8 +1165,21 @@ template <int MAXB, int SPECM> constexpr int fused_occ() { return MAXB > 2 ? 4 :
 #endif
 // TAB: the profile is read from a table (a user's callable evaluated on the x grid: hmvec/fft.py:56-94) instead of
 // evaluated from the family; everything behind the integrand is the same code.
+// In-kernel time stamps (diagnostic builds only: -DHMG_FR_STAMP; tools/probes/fused_stamps.py)
+#ifdef HMG_FR_STAMP
+__device__ long long g_fstamps[4096 * 16];
+#define FSTAMP(k) do { if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
 template <int NT, int MAXB, int MAXP, int SPECM, int ABL = HMG_ABL, bool TAB = false>
 __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, double* smem) {
+#ifdef HMG_FR_STAMP
+    const int fslot = (blockIdx.x % 29 == 0 && blockIdx.x / 29 < 4096) ? (int)(blockIdx.x / 29) : -1;
+    if (fslot >= 0 && threadIdx.x < 16) g_fstamps[fslot * 16 + threadIdx.x] = 0;
+    if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + 14] = (long long)wall_clock64();
+#endif
+    FSTAMP(0);
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
     // scratch, the broadcast mass norm and the left-fill counter.
@@ -1253,6 +1266,9 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // 0..374 only (3-of-5 butterflies, below) and the rest of the row need not even be cleared
     const bool lead3 = SPECM == 2500 && pruned && A.xs[2 * 375] > cm;
     const int pend = lead3 ? 375 : (pruned ? stride0 : M);
+#ifdef HMG_FR_STAMP
+    if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + 8] = (long long)__builtin_readcyclecounter() + (pend == 12345 ? 1 : 0);
+#endif
     double acc = 0.0;
     for (int p = threadIdx.x; p < pend; p += NT) {
         const int j = 2 * p;
@@ -1287,9 +1303,15 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // wave order - no second reduction stage.  The barrier also publishes buf and the row scalars the last
     // wavefront wrote (red[0..7] are written nowhere else, so nothing has to be waited for before).
     {
+#ifdef HMG_FR_STAMP
+        if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + 9] = (long long)__builtin_readcyclecounter() + (acc == 1.2345e300 ? 1 : 0);
+#endif
         const double ws = wave_sum(acc);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
         __syncthreads();
+#ifdef HMG_FR_STAMP
+        if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + 10] = (long long)__builtin_readcyclecounter();
+#endif
     }
     // The first wavefront adds the eight partials in wave order and forms the one number the rest of the row needs
     // from the norm: the scale of the unpack step, u_j = Im F_j * (-step / (mnorm kt_1)) / j.  It travels through
@@ -1302,6 +1324,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
     }
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
+    FSTAMP(1);
+#ifdef HMG_FR_STAMP
+    if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + 13] = jn;
+#endif
     if constexpr (ABL == 1 || ABL == 4) {     // timing experiments only: stop after phase A
         if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = buf[threadIdx.x].x + red[0];
         return;
@@ -1322,9 +1348,13 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
             if (lead3) fused_pass<NT, 5, 1, true, 3, 2>(buf, A.twM + 1, 2500, 4, 1, mg4, -1);
             else fused_pass<NT, 5, 1, true, 5, 2>(buf, A.twM + 1, 2500, 4, 1, mg4, -1);
         } else fused_pass<NT, 5, 1, true>(buf, A.twM + 1, 2500, 4, 1, mg4, -1);
+        FSTAMP(2);
         fused_pass<NT, 5, 1, true>(buf, A.twM + 5, 2500, 20, 1, mg20, -1);
+        FSTAMP(3);
         fused_pass<NT, 5, 1, true>(buf, A.twM + 25, 2500, 100, 1, mg100, -1);
+        FSTAMP(4);
         fused_pass<NT, 5, 1, true>(buf, A.twM + 125, 2500, 500, 1, mg500, 2 * jn + 2 < 500 ? jn : -1);
+        FSTAMP(5);
     } else if constexpr (SPECM != 0) {
         fused_passes_ct<NT, SPECM, 0>(buf, A.twM, pruned, jn);
     } else
@@ -1376,6 +1406,7 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     }
     if (threadIdx.x == 0) u[M - 1] = 0.0;  // Nyquist mode: Im F_M == 0
     __syncthreads();
+    FSTAMP(6);
     if constexpr (ABL == 3) {     // stop after phase C
         if (threadIdx.x < 8) A.out[(size_t)row * A.nk + threadIdx.x] = u[threadIdx.x];
         return;
@@ -1432,6 +1463,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
         A.nconst[row] = nleft;
         A.cconst[row] = u1 * pf;
     }
+    FSTAMP(7);
+#ifdef HMG_FR_STAMP
+    if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + 15] = (long long)wall_clock64();
+#endif
 }
 template <int NT, int MAXB, int MAXP, int SPECM>
 __global__ __launch_bounds__(NT, (fused_occ<MAXB, SPECM>())) void profile_fused_kernel(FusedArgs A) {
@@ -2735,6 +2770,11 @@ static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + blo
 
 // (definitions below inherit C linkage from the declarations in hmgrid.h)
 
+#ifdef HMG_FR_STAMP
+extern "C" int hmg_debug_stamps_fused(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hmg::g_fstamps), (size_t)n * sizeof(long long));
+}
+#endif
 int hmg_abi_version(void) { return HMG_ABI_VERSION; }
 const char* hmg_last_error(void) { return g_last_error.c_str(); }
 

@@ -9,6 +9,15 @@
 
 namespace hmg {
 
+// In-kernel time stamps (diagnostic builds only: -DHMG_LG_STAMP; tools/probes/long_stamps.py): thread 0 of every 29th
+// row workgroup records the shader clock at the phase boundaries of its row.
+#ifdef HMG_LG_STAMP
+__device__ long long g_stamps[4096 * 64];
+#define STAMP(k) do { if (stamp_slot >= 0 && threadIdx.x == 0) g_stamps[stamp_slot * 64 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- K45p: long radial grids with short support
 // nxs = 30000 / 40000 - what the reference's own callers pass (examples/lensing_baryons.py:27 and bin/tests.py:308:
 // add_battaglia_profile(xmax=50, nxs=30000); hmvec/params.py:59-60: numeric NFW, nxs = 40000, xmax = 200) - do not
@@ -96,6 +105,14 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     // profile_fused_row.  The packed samples of the row stay in REGISTERS: thread j < LP/R0 owns the R0 inputs
     // j + t LP/R0 of butterfly j of the first pass (radix R0, sub-transform size 1: no pass twiddles), so the
     // multiplication by W_M^{rp} and the first pass of every residue's transform need no LDS read at all.
+#ifdef HMG_LG_STAMP
+    const int stamp_slot = (blockIdx.x % 29 == 0 && blockIdx.x / 29 < 4096) ? (int)(blockIdx.x / 29) : -1;
+    if (stamp_slot >= 0 && threadIdx.x < 64) g_stamps[stamp_slot * 64 + threadIdx.x] = 0;
+#endif
+    STAMP(0);
+#ifdef HMG_LG_STAMP
+    if (stamp_slot >= 0 && threadIdx.x == 0) g_stamps[stamp_slot * 64 + 60] = (long long)wall_clock64();   // 100 MHz
+#endif
     cplx* buf = reinterpret_cast<cplx*>(smem);
     double* red = smem + 4 * (size_t)LP;
     int* s_cnt = reinterpret_cast<int*>(red + 17);
@@ -206,6 +223,10 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
     }
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
+    STAMP(1);
+#ifdef HMG_LG_STAMP
+    if (stamp_slot >= 0 && threadIdx.x == 0) { g_stamps[stamp_slot * 64 + 62] = jn; g_stamps[stamp_slot * 64 + 63] = row; }
+#endif
     // ---- phase B + C: per group of residues {g, R - g}: first pass from registers, the other passes in LDS,
     // unpack into the scratch line
     double* u = G.u + (size_t)(row - G.row0) * M;
@@ -233,7 +254,9 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                 }
             }
             __syncthreads();
+            STAMP(2);
             pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, -1);
+            STAMP(3);
             {   // product with the window's transform, fused into the first pass of the second transform
                 cplx v[MAXB0][4];
 #pragma unroll
@@ -256,7 +279,9 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                 }
                 __syncthreads();
             }
+            STAMP(4);
             pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, (2 * jn + 2 < nb_last_c) ? jn : -1);
+            STAMP(5);
             const double sc = red[24];
             double* __restrict__ ud = HMG_PRUNED_ULDS ? uls : u;
             for (int j = 1 + (int)threadIdx.x; j <= jn; j += NT) {
@@ -291,9 +316,11 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
             }
         }
         __syncthreads();                                       // (also publishes red[24] before the first unpack)
+        STAMP(8 + 3 * g);
 #if !(defined(HMG_LG_ABL) && (HMG_LG_ABL & 4))   // timing experiment: without the passes in LDS
         pruned_passes<NT, LP, 1>(buf, twl, nbuf, keep);
 #endif
+        STAMP(9 + 3 * g);
         const double sc = red[24];
 #if defined(HMG_LG_ABL) && (HMG_LG_ABL & 8)      // timing experiment: without the unpack step
         if (g == 0 && threadIdx.x < 64) u[threadIdx.x] = buf[threadIdx.x].x * sc;
@@ -303,6 +330,7 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         pruned_unpack(buf, LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, G.twNr, sc, u, (int)threadIdx.x, NT);
         if (nbuf == 2) pruned_unpack(buf, LP, R, M, s1, 1, 0, jn, G.twNr, sc, u, (int)threadIdx.x, NT);
         __syncthreads();                                       // the next group overwrites the buffers
+        STAMP(10 + 3 * g);
     }
     // A chirp row's modes sit by mode number - u_j at [j-1] - in LDS (or, without HMG_PRUNED_ULDS, in the scratch line);
     // the decomposition's in the scratch line by residue.  Mode M (Nyquist, Im F_M == 0) has no slot there: the
@@ -310,6 +338,7 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     if (HMG_PRUNED_ULDS && chirped) u = uls;                   // (jn <= Jw < M - 4: mode M is never read)
     else __threadfence_block();
     __syncthreads();                                           // u is read by other threads below
+    STAMP(6);
     // ---- phase D: as profile_fused_row, the modes read from the scratch line
     const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
     const double pf = A.post ? A.post[row] : 1.0;
@@ -366,6 +395,10 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         A.nconst[row] = nleft;
         A.cconst[row] = u1 * pf;
     }
+    STAMP(7);
+#ifdef HMG_LG_STAMP
+    if (stamp_slot >= 0 && threadIdx.x == 0) g_stamps[stamp_slot * 64 + 61] = (long long)wall_clock64();
+#endif
 }
 #ifndef HMG_PRUNED_OCC
 #define HMG_PRUNED_OCC 0
@@ -838,3 +871,9 @@ int launch_band(hipStream_t stream, int LB, PrunedArgs G, int rows, int jnmax) {
 }
 
 }  // namespace hmg
+
+#ifdef HMG_LG_STAMP
+extern "C" int hmg_debug_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hmg::g_stamps), (size_t)n * sizeof(long long));
+}
+#endif
