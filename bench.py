@@ -316,6 +316,21 @@ def readme_config2(ctx, with_cpu=True):
 # ------------------------------------------------------------------------------------------------
 # the radial grid the reference's own callers use (examples/lensing_baryons.py:27, bin/tests.py:308)
 # ------------------------------------------------------------------------------------------------
+def stage_stream(c2, stage, n=12):
+    """Milliseconds per call of a launch-only stage issued n times back to back between two events - no host
+    synchronisation in between, i.e. at the clock and cache state of a stream of passes (the eager, host-synchronised
+    stage times beside it start every launch from an idle GPU: 1.85 instead of 2.2 GHz measured inside the kernel)."""
+    for _ in range(3):
+        stage()
+    c2.sync()
+    c2.record(46)
+    for _ in range(n):
+        stage()
+    c2.record(47)
+    c2.sync()
+    return c2.elapsed_ms(46, 47) / n
+
+
 def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
     """add_battaglia_profile(xmax=50, nxs=30000) on the bench grid: milliseconds of the profile stage (HIP events)
     through the pruned long-grid route (+ chirp route for rows that need few modes) and through the chunked rocFFT
@@ -368,6 +383,8 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
                 out["ms_per_step"] = c2.elapsed_ms(46, 47) / K
                 out["ms_per_step_note"] = (f"HIP-graph replay of the whole pass with this profile, {K} replays between two events "
                                            "(the headline step with nxs = 5000 is timed the same way)")
+                out["pruned"]["profile_stage_ms_stream"] = stage_stream(
+                    c2, lambda: h2.add_battaglia_profile("electron", family="AGN", xmax=50, nxs=30000, ignore_existing=True))
                 # the numeric NFW branch at the reference's defaults (hmvec/params.py:59-60): nxs = 40000, xmax = 200
                 t_ = []
                 for i in range(2 + 5):
@@ -377,7 +394,9 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
                     if i >= 2:
                         t_.append(c2.elapsed_ms(44, 45))
                 out["numeric_nfw"] = {"profile": "add_nfw_profile(numeric=True): nxs=40000, xmax=200 (hmvec/params.py:59-60)",
-                                      "profile_stage_ms": float(np.median(t_))}
+                                      "profile_stage_ms": float(np.median(t_)),
+                                      "profile_stage_ms_stream": stage_stream(
+                                          c2, lambda: h2.add_nfw_profile("nfwnum", numeric=True, ignore_existing=True))}
             if route != "pruned_no_chirp":
                 tens[route] = h2.uk_profiles["electron"][::4, ::16]      # a strided sample of the (nz,nm,nk) tensor
             del h2
@@ -403,6 +422,9 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
                 if i >= 2:
                     t_.append(c2.elapsed_ms(44, 45))
             tsz[route] = {"profile_stage_ms": float(np.median(t_))}
+            if route == "narrow_band":
+                tsz[route]["profile_stage_ms_stream"] = stage_stream(
+                    c2, lambda: h2.add_battaglia_pres_profile("y", family="pres", xmax=2, nxs=30000, ignore_existing=True))
             pk[route] = h2.pk_profiles["y"][::4, ::16]
             del h2
             c2.close()
@@ -412,7 +434,9 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
     scale = np.max(np.abs(pk["rocfft"]), axis=-1, keepdims=True)
     tsz["max_dp_over_rowmax_between_routes"] = float(np.max(np.abs(pk["narrow_band"] - pk["rocfft"]) / scale))
     out["tsz_pressure"] = tsz
-    out["note"] = ("pass_wall_ms_eager: one pass = mass function + NFW + this profile + HOD + the batched spectra, eager "
+    out["note"] = ("profile_stage_ms: HIP events around ONE launch after a host synchronisation (the GPU starts it from idle clocks); "
+                   "profile_stage_ms_stream: the same stage issued 12 times back to back between two events, per call - the state a "
+                   "stream of passes (and the graph replay behind ms_per_step) runs in.  pass_wall_ms_eager: one pass = mass function + NFW + this profile + HOD + the batched spectra, eager "
                    "launches, host-synchronised after every pass (the headline ms_per_step is a HIP-graph replay); "
                    "tolerance on u is 1e-12 absolute (tests/test_gpu_longgrid.py holds both routes to the reference's "
                    "own fixture case_f)")

@@ -21,6 +21,11 @@ KERNELS = [   # (label, regex on the mangled name)
     ("profile_pruned_kernel<512,1250>  (nxs = 40000)", r"profile_pruned_kernelILi512ELi1250E"),
     ("profile_band_kernel<512,1000,1>  (tSZ: nxs = 30000, xmax = 2, <= 255 modes)", r"profile_band_kernelILi512ELi1000ELi1E"),
     ("profile_band_kernel<512,1000,2>  (the same, up to 499 modes)", r"profile_band_kernelILi512ELi1000ELi2E"),
+    ("profile_group_kernel<1,2,1500>  (nxs = 3000, compile-time plan, round 5)", r"profile_group_kernelILi1ELi2ELi1500E"),
+    ("profile_group_kernel<3,3,3000>  (nxs = 6000 as one row, round 5)", r"profile_group_kernelILi3ELi3ELi3000E"),
+    ("profile_group_kernel<2,3,0>  (run-time plan)", r"profile_group_kernelILi2ELi3ELi0E"),
+    ("profile_table_kernel<512,2,3,2500>  (user callable, nxs = 5000, round 5)", r"profile_table_kernelILi512ELi2ELi3ELi2500E"),
+    ("profile_table_kernel<512,2,4,0>  (user callable, run-time plan)", r"profile_table_kernelILi512ELi2ELi4ELi0E"),
     ("stand-alone: profile_fused_kernel<512,2,3,2500>", r"profile_fused_kernelILi512ELi2ELi3ELi2500E"),
     ("stand-alone: nfw_kernel", r"10nfw_kernelE"),
 ]
