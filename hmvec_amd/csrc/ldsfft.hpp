@@ -234,18 +234,14 @@ HMG_HD void pass_load(const cplx* buf, const cplx* twM, int M, int Ns, int twste
     const int k = j - mul_idx<SMALL>((int)div_ns<SMALL>((unsigned)j, magic), Ns);      // j mod Ns
     const int stride = M / R;
     v[0] = buf[j >> SRC_SHIFT];
-    // one table read (w = W^(k M/(Ns R))); the higher powers by complex multiplication
-    // (<= 3 products, a few ulp) instead of R-1 trips to the L2-resident table (measured on MI355X in round 3,
-    // all powers read from the table: the fused profile kernel goes from 0.204 to 0.245 ms - a 16-byte-per-lane
-    // load occupies the CU's one vector-memory return path for 16 cycles, the 12 multiply-adds it saves cost 48
-    // cycles on one of four SIMDs).
+    // one table read (w = W^(k M/(Ns R)): element k of the pass's slice when the caller hands in a per-pass table and
+    // twstep = 1); the higher powers by complex multiplication (<= 3 products, a few ulp) instead of R-1 trips to the
+    // table (measured on MI355X in round 3, all powers read: the fused profile kernel goes from 0.204 to 0.245 ms - even
+    // a coalesced 16-byte-per-lane load occupies the CU's one vector-memory path for 16 cycles, the 12 multiply-adds it
+    // saves cost 48 cycles on one of four SIMDs).
     // k == 0 is not special-cased: its twiddle is twM[0] = 1 exactly, and a branch would make
     // every wavefront that holds such a lane walk both paths.
-#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 1)      // timing experiment: no twiddle fetch in the passes
-    const cplx w1 = cplx{0.6 + 1e-9 * k, 0.8};
-#else
     const cplx w1 = twM[mul_idx<SMALL>(k, twstep)];
-#endif
     cplx w = w1;
 #pragma unroll
     for (int t = 1; t < NIN; ++t) {
