@@ -320,6 +320,7 @@ class Context:
         self.capture_serial = 0       # changes at every capture begin/end: events recorded before are off limits
         self._deferred = []           # objects with stages queued for a grouped launch (HaloModel), in order
         self._trace = None            # list of (name, args) while Context.trace records a launch-only sequence
+        self.shared = {}              # id(read-only host array) -> (array, device copies ...): inputs several models share
 
     # deferred stages: a HaloModel queues the launch-only stages of a pass so that independent ones can
     # share a launch (hmg_group_*); ANY other native call of this context issues them first, so program
@@ -360,6 +361,7 @@ class Context:
             check(getattr(lib, name)(h, *args))
 
     def close(self):
+        self.shared = {}
         if getattr(self, "handle", None):
             self.lib.hmg_ctx_destroy(self.handle)
             self.handle = None

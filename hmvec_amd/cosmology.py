@@ -82,6 +82,7 @@ def sigma2_weights(kq):
     return w
 
 
+_PLIN_CACHE = []        # (shared grid object, parameter + redshift key, P(z,k)): Cosmology.P_lin_approx
 _TK_CACHE = []          # (grid object, parameter key, grid stamp, T(k), scalars): Cosmology.Tk
 
 
@@ -294,6 +295,18 @@ class Cosmology(object):
         """Primordial power x growth^2 x T^2 (hmvec/cosmology.py:391-402)."""
         zs = np.atleast_1d(zs)
         ks = np.asarray(ks)
+        # the whole product on a SHARED k grid (sigma2_kgrid: one read-only object per parameter set) is kept too: a
+        # loop that builds model after model on one cosmology then skips 200 000 multiplications and, through the
+        # identity of the returned array, the upload and layout of P(k',z) on the device (HaloModel.init_mass_function)
+        ckey = None
+        if isinstance(ks, np.ndarray) and not ks.flags.writeable:
+            p_ = self.params
+            ckey = (type, float(self.h), float(p_["omch2"]), float(p_["ombh2"]), float(self.omm0), float(self.oml0),
+                    float(p_["As"]), float(p_["ns"]), float(p_["pivot_scalar"]), float(p_["H0"]), float(self.get_Omega_nu()),
+                    zs.tobytes())
+            for ent in _PLIN_CACHE:
+                if ent[0] is ks and ent[1] == ckey:
+                    return ent[2]
         tk = self.Tk(ks, type=type)[None, :]
         Dz = self.D_growth(1 / (1 + zs), type="anorm")[:, None]
         kp, ns = self.params["pivot_scalar"], self.params["ns"]
@@ -301,7 +314,12 @@ class Cosmology(object):
                 + self.get_Omega_nu() * self.params["H0"] ** 2.0)
         kfac = (ks / kp) ** (ns - 1.0) * ks
         pref = 8 * np.pi ** 2 * self.params["As"] / 25.0 / omh2 ** 2.0 * cspeed ** 4.0
-        return pref * kfac[None, :] * Dz ** 2.0 * tk ** 2.0      # (the reference's order of products: same bits)
+        out = pref * kfac[None, :] * Dz ** 2.0 * tk ** 2.0       # (the reference's order of products: same bits)
+        if ckey is not None:
+            out.setflags(write=False)
+            _PLIN_CACHE.insert(0, (ks, ckey, out))
+            del _PLIN_CACHE[4:]
+        return out
 
     # ------------------------------------------------------------------ Boltzmann-code P(k) (row N3)
     def get_pk_interpolator(self, zs, kmax, var="weyl", nonlinear=False, **kwargs):

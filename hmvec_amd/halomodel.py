@@ -441,13 +441,23 @@ class HaloModel(Cosmology):
             else:
                 self.sPzk = self.P_lin_approx(kq, self.zs)
             wq = sigma2_weights(kq)
-            d_sP = ctx.upload(self.sPzk)
-            # P(k',z) is an input of the path: lay it out once as the contraction reads it
-            n = C.c_size_t()
-            nat.check(ctx.lib.hmg_sigma2_layout_size(nz, kq.size, C.byref(n)))
-            d_PT = ctx.empty((n.value,))
-            ctx.call("hmg_sigma2_prepare", nz, kq.size, d_sP.ptr, d_PT.ptr)
-            self._dcache["sig_in"] = (d_PT,) + tuple(ctx.upload(a) for a in (kq, wq, self.R_of_m(ms)))
+            # P(k',z) is an input of the path: uploaded and laid out once as the contraction reads it - once per
+            # MODEL, or once per host array when the provider hands out the same read-only array again (the analytic
+            # provider does for a repeated cosmology: Cosmology.P_lin_approx), together with the grid and its weights
+            shared = ctx.shared.get(id(self.sPzk)) if not self.sPzk.flags.writeable else None
+            if shared is None or shared[0] is not self.sPzk:
+                d_sP = ctx.upload(self.sPzk)
+                n = C.c_size_t()
+                nat.check(ctx.lib.hmg_sigma2_layout_size(nz, kq.size, C.byref(n)))
+                d_PT = ctx.empty((n.value,))
+                ctx.call("hmg_sigma2_prepare", nz, kq.size, d_sP.ptr, d_PT.ptr)
+                shared = (self.sPzk, d_PT, ctx.upload(kq), ctx.upload(wq))
+                if not self.sPzk.flags.writeable:
+                    if len(ctx.shared) >= 4:
+                        ctx.flush()           # (queued stages of other models may hold addresses of an evicted entry)
+                        ctx.shared.clear()
+                    ctx.shared[id(self.sPzk)] = shared
+            self._dcache["sig_in"] = shared[1:] + (ctx.upload(self.R_of_m(ms)),)
         d_PT, d_kq, d_wq, d_R = self._dcache["sig_in"]
         self._sync_point()               # start of a pass: everything launched so far precedes it
         ctx = self._aux()
@@ -991,6 +1001,8 @@ class HaloModel(Cosmology):
                 {("uk", hod["central_profile"])} if hod["central_profile"] is not None else set())
         return {("uk" if k1 == "m" else "pk", nm_)}
 
+    _SMALL_GRID_BYTES = 32 << 20       # tensors up to this size: every registered tracer rides in the first batch
+
     def _free_riders(self, name, name2):
         """Other registered tracers whose tensors are a subset of what (name, name2) streams
         anyway: their spectra with each other and with the requested pair cost no extra HBM
@@ -1002,11 +1014,15 @@ class HaloModel(Cosmology):
         need = need | need2
         kinds = {}
         names = [name] + ([name2] if name2 != name else [])
+        # On a small grid (a tensor below 32 MB: the README grid's are 32 MB for all three) a tensor more in the batch
+        # costs microseconds while a batch more costs a launch and a result copy: every registered tracer rides along
+        # in the first request.  On a large grid only those whose tensors are streamed anyway.
+        small = self._nz * self._nm * self._nk * 8 <= self._SMALL_GRID_BYTES
         for cand in list(self.hods) + list(self.uk_profiles) + list(self.pk_profiles):
             if cand in names or len(names) >= 4:
                 continue
             tn = self._tensor_names(cand)
-            if tn is not None and tn <= need:
+            if tn is not None and (tn <= need or small):
                 names.append(cand)
         for n_ in names:
             kinds[n_] = self._tracer(n_, "hmp")[1]

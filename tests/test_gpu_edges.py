@@ -136,11 +136,15 @@ def test_spectrum_cache_is_invalidated_by_state_changes():
     assert not np.allclose(h.get_power_1halo("g"), g1)
 
 
-def test_free_rider_batching_matches_single_pair_kernel():
+@pytest.mark.parametrize("small_grid_rule", [False, True])
+def test_free_rider_batching_matches_single_pair_kernel(small_grid_rule, monkeypatch):
     """A get_power_* call computes, in the same pass, every other pair whose tensors are already
-    being streamed; all of them must agree with the single-pair kernel, including for two
-    different HOD names (kept on the per-pair path) and the (b, a) ordering."""
+    being streamed - on a small grid (round 5: tensors up to 32 MB, where another tensor in the batch costs less than
+    another launch and result copy) every registered tracer; all of them must agree with the single-pair kernel,
+    including for two different HOD names (kept on the per-pair path) and the (b, a) ordering."""
     import hmvec_amd as hm
+    if not small_grid_rule:
+        monkeypatch.setattr(hm.HaloModel, "_SMALL_GRID_BYTES", 0)      # the large-grid rule on this little grid
     zs = np.array([0.3, 0.9, 1.6])
     ms = np.geomspace(1e11, 1e16, 24)
     ks = np.geomspace(1e-3, 20, 40)
@@ -157,7 +161,7 @@ def test_free_rider_batching_matches_single_pair_kernel():
     v = h._version
     p = h.get_power_1halo("nfw")                      # streams only the nfw tensor ...
     assert ("g", "nfw") in h._pcache and ("g", "g") in h._pcache      # ... g rides along for free
-    assert ("electron", "electron") not in h._pcache                   # a second tensor does not
+    assert (("electron", "electron") in h._pcache) == small_grid_rule   # a second tensor only on a small grid
     for a in names:
         for b in names:
             assert np.allclose(h.get_power_1halo(a, b), ref[(a, b)][0], rtol=1e-12, atol=0), (a, b)
