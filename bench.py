@@ -371,10 +371,10 @@ def long_grid_block(ctx, zs, ms, ks, mthr, pairs, reps=12):
             if route == "pruned":
                 # the same pass as ONE captured step, replayed: the number that compares with the headline ms_per_step
                 gid = c2.capture(lambda: one(False))
-                for _ in range(3):
+                for _ in range(64):               # (the same clock / cache preconditioning as the headline loop)
                     c2.replay(gid)
                 c2.sync()
-                K = 20
+                K = 40
                 c2.record(46)
                 for _ in range(K):
                     c2.replay(gid)
