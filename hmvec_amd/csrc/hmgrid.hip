@@ -3736,7 +3736,6 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, bool ca
     G.F.twN = PP->twN;
     G.M = M; G.R = M / LP; G.twB = PP->twB; G.twL = twL; G.u = (double*)c->scratch[0]; G.fault = c->d_fault; G.row0 = 0;
     G.twR = PR->twR; G.twNr = PR->twNr; G.rmagic = (unsigned)(4294967296ull / (unsigned)G.R) + 1u;
-    G.lpt_nz = 0;
     G.chP = G.chJ = G.Bw = G.twC = nullptr;
     G.Jw = 0; G.p0 = 0;
     if (c->use_chirp && (LP == 1000 || LP == 1250) && p0max >= 1) {

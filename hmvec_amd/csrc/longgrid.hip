@@ -3,8 +3,6 @@
 // A translation unit of its own (see the note in hmgrid.hip where this code used to be).  Design: DESIGN.md section 3.
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "longgrid.hpp"
 
 namespace hmg {
@@ -54,31 +52,6 @@ __device__ __forceinline__ void pruned_passes(cplx* buf, const cplx* twL, int nb
         pruned_passes<NT, LP, PS + 1, NBUF>(buf, twL, nbuf, keep);
     }
 }
-// The same with a share of other work in the load half of every pass: hook(integral_constant<int, i>) runs between
-// the loads of pass i + 1 and its barrier - arithmetic that needs no LDS, issued while the wavefront's reads are in
-// flight and the other wavefronts arrive (the narrow-band kernel evaluates the NEXT round's integrand samples there).
-template <int NT, int LP, int PS, int NBUF, class Hook>
-__device__ __forceinline__ void pruned_passes_hook(cplx* buf, const cplx* twL, int nbuf, int keep, Hook& hook) {
-    if constexpr (PS < SubPass<LP, 0>::P.npass) {
-        using S = SubPass<LP, PS>;
-        constexpr int MAXB = (NBUF * S::nb + NT - 1) / NT;
-        cplx v[MAXB][S::R];
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            const int jj = threadIdx.x + b * NT;
-            if (sub_pass_active<LP, PS>(jj, nbuf, keep)) sub_pass_load<LP, PS>(buf, twL, jj, v[b]);
-        }
-        hook(std::integral_constant<int, PS - 1>{});
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            const int jj = threadIdx.x + b * NT;
-            if (sub_pass_active<LP, PS>(jj, nbuf, keep)) sub_pass_store<LP, PS>(buf, jj, v[b]);
-        }
-        __syncthreads();
-        pruned_passes_hook<NT, LP, PS + 1, NBUF>(buf, twL, nbuf, keep, hook);
-    }
-}
 // lengths whose chirp route is compiled in: the thread that owns the samples j, j + LP/2 of the decomposition's
 // radix-2 first pass owns exactly the two non-zero inputs of butterfly j of the radix-4 first pass at Lc = 2 LP
 template <int LP> constexpr bool chirp_ok() {
@@ -88,9 +61,6 @@ template <int LP> constexpr bool chirp_ok() {
 
 #ifndef HMG_PRUNED_ULDS
 #define HMG_PRUNED_ULDS 1
-#endif
-#ifndef HMG_PRUNED_LPT
-#define HMG_PRUNED_LPT 0
 #endif
 // LDS of a row workgroup: [0, 2 LP) cplx transform buffers | 32 doubles of scalars | the modes of a chirp row
 // (rows with more modes than fit take the decomposition)
@@ -413,17 +383,7 @@ template <int NT, int LP> constexpr int pruned_occ() {
 template <int NT, int LP>
 __global__ __launch_bounds__(NT, (pruned_occ<NT, LP>())) void profile_pruned_kernel(PrunedArgs G) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // Heavy rows first: the cost of a row grows with the modes it needs, jn ~ r_s (1+z), i.e. with the mass - and the
-    // rows of a launch are laid out [z][m], m ascending.  Walking the masses downwards across all redshifts
-    // (block b -> z = b mod nz, m = nm - 1 - b / nz) hands the rows that take the decomposition out first and leaves
-    // the cheap chirp rows for the end of the launch, where they fill the tail (a launch covering whole redshifts only).
-    int b = blockIdx.x;
-    if (HMG_PRUNED_LPT && G.row0 == 0 && G.lpt_nz > 0) {
-        const int nz = G.lpt_nz, nm = G.F.nm;
-        const int q = b / nz;
-        b = (b - q * nz) * nm + (nm - 1 - q);
-    }
-    profile_pruned_row<NT, LP>(G, G.row0 + b, smem);
+    profile_pruned_row<NT, LP>(G, G.row0 + blockIdx.x, smem);
 }
 
 // ---- Rows whose support does not prune but which need few modes: the narrow-band route (ldsfft.hpp).  The tSZ notebook
@@ -441,9 +401,6 @@ __global__ __launch_bounds__(NT, (pruned_occ<NT, LP>())) void profile_pruned_ker
 // contiguous again (G.u holds the tables: 3 nxs doubles).  w_n = (x_{n+1} - x_{n-1})/2 with the one-sided ends of np.trapz.
 #ifndef HMG_BAND_NBUF
 #define HMG_BAND_NBUF 2
-#endif
-#ifndef HMG_BAND_PIPE
-#define HMG_BAND_PIPE 0
 #endif
 __global__ void band_tables_kernel(int nxs, int D, int LB, const double* __restrict__ xs, const double* __restrict__ logx,
                                    double2* __restrict__ xT, double2* __restrict__ lT, double2* __restrict__ wT) {
@@ -554,87 +511,6 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
     const double2* __restrict__ lT = xT + M;
     const double2* __restrict__ wT = lT + M;
     double nrm = 0.0;
-    if constexpr (HMG_BAND_PIPE && MAXB0 == 1) {
-    // Software pipeline over the rounds: the integrand samples of round r + 1 are evaluated - pair by pair, into
-    // registers - in the load halves of round r's passes, where a wavefront otherwise waits for its LDS reads and for
-    // the other wavefronts at the barrier: the transcendentals (two thirds of this kernel's arithmetic) then run
-    // under the LDS traffic of the passes instead of beside it.  Same samples, same order of every sum: same bits.
-    // (lengths with one first-pass butterfly per thread: LB = 1000, 1024; LB = 1250 keeps the plain loop below)
-    constexpr int NPAIR = HMG_BAND_NBUF * R0;                       // packed pairs a thread owns per round
-    constexpr int NHOOK = S0::P.npass - 1;                          // passes in LDS = hook slots
-    constexpr int PPH = (NPAIR + NHOOK - 1) / NHOOK;                // pairs per slot
-    cplx vn[HMG_BAND_NBUF][R0];
-    const int jb = threadIdx.x;
-    int nb_next = 0, p1_next = 0;
-    auto eval_pair = [&](int h, int t) {                            // (h, t compile-time after unrolling)
-        cplx out{0.0, 0.0};
-        if (h < nb_next && jb < nb0) {
-            const int q = (p1_next + h) * LB + jb + t * nb0;        // pair p = p1 + h + D p2, p2 = jb + t nb0
-            const double2 xv = xT[q], lv = lT[q], wv = wT[q];
-            double r0 = 0.0, r1 = 0.0;
-            if (alpha1) {
-                if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_alpha1(lv.x - ln_xc, xv.x * inv_xc, Aamp, EX, A.gamma);
-                if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_alpha1(lv.y - ln_xc, xv.y * inv_xc, Aamp, EX, A.gamma);
-            } else {
-                if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(lv.x - ln_xc, Aamp, AL, EX, A.gamma);
-                if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(lv.y - ln_xc, Aamp, AL, EX, A.gamma);
-            }
-            out = cplx{xv.x * r0, xv.y * r1};
-            if (A.do_norm && (r0 != 0.0 || r1 != 0.0))
-                nrm += wv.x * (r0 * (xv.x * xv.x)) + wv.y * (r1 * (xv.y * xv.y));
-        }
-        vn[h][t] = out;
-    };
-    auto hook = [&](auto slot) {
-        constexpr int I = decltype(slot)::value;
-#pragma unroll
-        for (int k = 0; k < PPH; ++k) {
-            constexpr int dummy = 0; (void)dummy;
-            const int pi = I * PPH + k;
-            if (pi < NPAIR) eval_pair(pi / R0, pi % R0);
-        }
-    };
-    nb_next = (HMG_BAND_NBUF == 2 && 1 < D) ? 2 : 1;                // round 0: evaluated up front
-#pragma unroll
-    for (int pi = 0; pi < NPAIR; ++pi) eval_pair(pi / R0, pi % R0);
-    for (int p1 = 0; p1 < D; p1 += HMG_BAND_NBUF) {
-        const int nbuf = (HMG_BAND_NBUF == 2 && p1 + 1 < D) ? 2 : 1;
-        if (jb < nb0) {
-#pragma unroll
-            for (int h = 0; h < HMG_BAND_NBUF; ++h) {
-                if (h < nbuf) {
-                    cplx v[R0];
-#pragma unroll
-                    for (int t = 0; t < R0; ++t) v[t] = vn[h][t];
-                    dft_small<R0>(v);
-#pragma unroll
-                    for (int t = 0; t < R0; ++t) buf[h * LB + jb * R0 + t] = v[t];
-                }
-            }
-        }
-        __syncthreads();
-        p1_next = p1 + HMG_BAND_NBUF;
-        nb_next = p1_next < D ? ((HMG_BAND_NBUF == 2 && p1_next + 1 < D) ? 2 : 1) : 0;
-        pruned_passes_hook<NT, LB, 1, HMG_BAND_NBUF>(buf, G.twL, nbuf, keep, hook);
-        const cplx* __restrict__ twm = G.twR + (size_t)p1 * LB;
-#pragma unroll
-        for (int a = 0; a < MAXA; ++a) {
-            const int t = threadIdx.x + a * NT;
-            if (t < nslot) {
-                const int j = band_mode(t, jn), idx = band_index(j, LB), ja = j < 0 ? -j : j;
-                cplx w = twm[ja];                                                  // W_M^(p1 j): residue p1 ...
-                if (j < 0) w.y = -w.y;
-                acc[a] = cadd(acc[a], cmul(buf[idx], w));
-                if (nbuf == 2) {
-                    w = twm[LB + ja];                                              // ... then p1 + 1: the same order of sums
-                    if (j < 0) w.y = -w.y;
-                    acc[a] = cadd(acc[a], cmul(buf[LB + idx], w));
-                }
-            }
-        }
-        __syncthreads();                                       // the next residues' first pass overwrites the buffers
-    }
-    } else {
     for (int p1 = 0; p1 < D; p1 += HMG_BAND_NBUF) {
         const int nbuf = (HMG_BAND_NBUF == 2 && p1 + 1 < D) ? 2 : 1;
         // first pass (radix R0, sub-transform size 1) of the decimated rows z[p1 + h + D p2], straight from the integrand
@@ -695,7 +571,6 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
             }
         }
         __syncthreads();                                       // the next residues' first pass overwrites the buffers
-    }
     }
     // mass norm (the order of the partial sums differs from the one-row kernel: per thread over its samples of all
     // residues, then wavefronts in order) and the scale of the unpack step
@@ -804,7 +679,6 @@ __global__ void profile_support_kernel(int rows, int nxs, const double* __restri
 template <int LP>
 static int launch_pruned_lp(hipStream_t stream, PrunedArgs G, int rows, size_t rows_per_launch) {
     const size_t lds = pruned_lds_bytes<LP>();
-    G.lpt_nz = (rows_per_launch >= (size_t)rows && G.F.nm > 0 && rows % G.F.nm == 0) ? rows / G.F.nm : 0;
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute((const void*)profile_pruned_kernel<LONG_NT, LP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -22,7 +22,6 @@ struct PrunedArgs {
     const cplx* Bw;       // transform of the chirp window / Lc, Lc = 2 LP
     const cplx* twC;      // per-pass twiddle table of the length-Lc plan
     int Jw, p0;           // modes |j| <= Jw are in the window; it was built for supports of <= p0 packed samples
-    int lpt_nz;           // set by launch_pruned: redshifts of a launch that covers whole redshifts (heavy rows first), else 0
 };
 
 #ifndef HMG_LONG_NT
