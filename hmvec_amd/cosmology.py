@@ -86,14 +86,23 @@ _PLIN_CACHE = []        # (shared grid object, parameter + redshift key, P(z,k))
 _TK_CACHE = []          # (grid object, parameter key, grid stamp, T(k), scalars): Cosmology.Tk
 
 
-def _grid_stamp(ks):
-    """Cheap guard against a grid array that was modified in place after it was cached: its length, ends, middle and sum
-    of three more elements."""
+def _grid_identity(ks):
+    """What identifies a k grid in the caches: a READ-ONLY array by the object itself (its contents cannot change under
+    us - sigma2_kgrid hands such arrays out), a writable one by its bytes (a user's 1001-point grid: 8 KB, compared in a
+    microsecond; a grid modified in place is then simply another grid).  None: not cached (not an array, or > 1 MB)."""
     if not isinstance(ks, np.ndarray) or ks.size == 0:
         return None
-    n = ks.size
-    f = ks.reshape(-1)
-    return (n, float(f[0]), float(f[-1]), float(f[n // 2]), float(f[n // 3] + f[n // 5] + f[(2 * n) // 3]))
+    if not ks.flags.writeable:
+        return ks
+    if ks.nbytes > (1 << 20) or ks.dtype != np.float64:
+        return None
+    return (ks.shape, ks.tobytes())
+
+
+def _same_grid(a, b):
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return a is b
+    return a == b
 
 
 class Cosmology(object):
@@ -217,19 +226,20 @@ class Cosmology(object):
 
         The value is a function of (omch2, ombh2, h, omm0) and the k grid only; a sweep builds model after model on
         the same grids (the README sequence in a loop spends a quarter of its host time here), so the last few
-        results are kept - keyed by those numbers and by the grid OBJECT (an entry holds a reference to its grid, so
-        the identity test cannot be fooled by a recycled address; a caller that passes equal values in a new array
-        simply misses)."""
+        results are kept - keyed by those numbers and by the grid: a read-only array by identity, a writable one by
+        its bytes (_grid_identity)."""
         key = (type, float(self.h), float(self.params["omch2"]), float(self.params["ombh2"]), float(self.omm0))
-        for ent in _TK_CACHE:
-            if ent[0] is ks and ent[1] == key and ent[2] == _grid_stamp(ks):
-                (self.tcmb, self._k_eq, self._z_eq, self._z_d, self._R_d, self._R_eq, self.sh_d, self._k_silk) = ent[4]
-                return ent[3]
+        ident = _grid_identity(ks)
+        if ident is not None:
+            for ent in _TK_CACHE:
+                if ent[1] == key and _same_grid(ent[0], ident):
+                    (self.tcmb, self._k_eq, self._z_eq, self._z_d, self._R_d, self._R_eq, self.sh_d, self._k_silk) = ent[3]
+                    return ent[2]
         tk = self._Tk_eval(ks, type)
-        if isinstance(ks, np.ndarray):
+        if ident is not None:
             tk.setflags(write=False)
-            _TK_CACHE.insert(0, (ks, key, _grid_stamp(ks), tk, (self.tcmb, self._k_eq, self._z_eq, self._z_d, self._R_d,
-                                                                 self._R_eq, self.sh_d, self._k_silk)))
+            _TK_CACHE.insert(0, (ident, key, tk, (self.tcmb, self._k_eq, self._z_eq, self._z_d, self._R_d, self._R_eq,
+                                                  self.sh_d, self._k_silk)))
             del _TK_CACHE[8:]
         return tk
 

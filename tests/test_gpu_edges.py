@@ -169,6 +169,43 @@ def test_free_rider_batching_matches_single_pair_kernel(small_grid_rule, monkeyp
     assert h._version == v and np.array_equal(p, h.get_power_1halo("nfw"))
 
 
+def test_results_handed_out_are_the_callers_own_and_shared_inputs_survive_eviction():
+    """Round 5 host-side sharing.  (a) A batch of spectra reaches the host in one copy and every get_power_* call hands
+    out an array of the caller's own, as the reference does: writing into one result changes no later one.  (b) The device
+    layout of P(k',z) is shared by models that are handed the same read-only host array (a loop over one cosmology) and
+    the context keeps a few of them: six cosmologies in turn on one context, then the first again - every model equals
+    what a fresh context computes."""
+    import hmvec_amd as hm
+    from hmvec_amd import _native as nat
+    zs = np.array([0.2, 1.1]); ms = np.geomspace(1e11, 1e16, 24); ks = np.geomspace(1e-3, 20, 40)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    a = h.get_power_1halo("nfw")
+    keep = a.copy()
+    a *= 0.0                                            # the caller scribbles over its array ...
+    b = h.get_power_1halo("nfw")
+    assert np.array_equal(b, keep) and b is not a        # ... the next call is not affected
+    b += 1.0
+    assert np.array_equal(h.get_power_1halo("nfw"), keep) and np.array_equal(h.get_power("nfw"), keep + h.get_power_2halo("nfw"))
+
+    def spectrum(ctx, omch2):
+        m = hm.HaloModel(zs, ks, ms=ms, params={"omch2": omch2}, accuracy="low", engine="analytic", ctx=ctx)
+        return m.get_power("nfw"), m
+    fresh = {}
+    for w in (0.10, 0.11, 0.12, 0.13, 0.14, 0.15):
+        c = nat.Context(0)
+        fresh[w] = spectrum(c, w)[0]
+        c.close()
+    ctx = nat.Context(0)
+    models = []
+    for w in (0.10, 0.11, 0.12, 0.13, 0.14, 0.15, 0.10, 0.13):
+        p, m = spectrum(ctx, w)
+        models.append(m)                                 # (earlier models stay alive while entries are evicted)
+        assert np.array_equal(p, fresh[w]), w
+    assert len(ctx.shared) <= 4
+    assert np.array_equal(models[0].get_power("nfw"), fresh[0.10])
+    ctx.close()
+
+
 def test_ksz_consumer_call_sequence():
     """Row N4: the call sequence of the largest in-repo consumer of the path, kSZ.__init__
     (hmvec/ksz.py:123-141,161-162,196-197): ctor with params=None, add_battaglia_profile by

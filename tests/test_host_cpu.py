@@ -74,6 +74,43 @@ def test_host_cosmology_reproduces_reference_inputs(case):
     assert abs(cos.h - float(g["in_h"])) < 1e-15 and abs(cos.omm0 - float(g["in_omm0"])) < 1e-15
 
 
+def test_provider_caches_return_what_a_fresh_evaluation_returns():
+    """Round 5: Cosmology.Tk keeps its last results per (parameters, grid OBJECT), P_lin_approx the whole product on the
+    shared read-only sigma^2 grid (by identity; writable grids by their bytes).  Alternating two cosmologies on the same
+    grids, a grid modified in place between calls, equal values in a new array: every answer equals the uncached
+    evaluation bit for bit."""
+    from hmvec_amd import cosmology as cm
+    pa = merged_params({})
+    pb = merged_params({"omch2": 0.11, "ns": 0.97, "As": 2.3e-9})
+    zs = np.array([0.0, 0.7, 2.1])
+    kq = cm.sigma2_kgrid(pa["sigma2_kmin"], pa["sigma2_kmax"], pa["sigma2_numks"])
+    assert kq is cm.sigma2_kgrid(pa["sigma2_kmin"], pa["sigma2_kmax"], pa["sigma2_numks"]) and not kq.flags.writeable
+    ks = np.geomspace(1e-4, 50, 301)
+
+    def fresh(p, k):
+        cm._TK_CACHE.clear(); cm._PLIN_CACHE.clear()
+        c = Cosmology(p, accuracy="low", engine="analytic")
+        return c.Tk(k).copy(), c.P_lin_approx(k, zs).copy()
+
+    want = {(n, g): fresh(p, k) for n, p in (("a", pa), ("b", pb)) for g, k in (("q", kq), ("k", ks))}
+    cm._TK_CACHE.clear(); cm._PLIN_CACHE.clear()
+    ca, cb = (Cosmology(p, accuracy="low", engine="analytic") for p in (pa, pb))
+    for _ in range(3):                                   # hits after the first round
+        for n, c in (("a", ca), ("b", cb)):
+            for g, k in (("q", kq), ("k", ks)):
+                assert np.array_equal(c.Tk(k), want[(n, g)][0]) and np.array_equal(c.P_lin_approx(k, zs), want[(n, g)][1])
+    first = ca.P_lin_approx(kq, zs)
+    assert ca.P_lin_approx(kq, zs) is first and not first.flags.writeable     # the shared product itself, read-only
+    assert ca.P_lin_approx(ks, zs) is not ca.P_lin_approx(ks, zs)               # a user's grid: a fresh array every time
+    assert not np.array_equal(ca.P_lin_approx(kq, zs + 0.1), first)             # other redshifts: another entry
+    k2 = ks.copy()
+    t1 = ca.Tk(k2).copy()
+    assert np.array_equal(ca.Tk(ks.copy()), t1)          # equal values in a new writable array: found by content
+    k2[10] *= 1.5                                        # the same OBJECT, ONE element changed in place: another grid
+    t2 = ca.Tk(k2)
+    assert not np.array_equal(t1, t2) and np.array_equal(t2, ca._Tk_eval(k2, "eisenhu_osc"))
+
+
 def test_background_distances_consistent():
     bg = AnalyticBackground(67.3, 0.02225, 0.1198)
     z = np.array([0.0, 0.5, 2.0])
