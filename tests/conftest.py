@@ -58,3 +58,16 @@ def power_close(P, Pref, rtol=1e-8, atol_frac=1e-12):
     tol = rtol * np.abs(Pref) + atol_frac * np.max(np.abs(Pref), axis=-1, keepdims=True)
     bad = np.abs(P - Pref) > tol
     return not bad.any(), float(np.max(np.abs(P - Pref) / np.maximum(tol, 1e-300)))
+
+
+ROUTE_SWITCHES = ("HMG_FUSED_FFT", "HMG_PRUNED_FFT", "HMG_BAND_FFT", "HMG_CHIRP", "HMG_FUSED_GENERIC", "HMG_NO_HINTS",
+                  "HMG_PRUNED_LP_MIN", "HMG_FUSED_MAX_M", "HMG_FUSED_PREFER_M")
+
+
+@pytest.fixture
+def default_routes(monkeypatch):
+    """For tests that are ABOUT one route of hmg_profile_fft (its bound, its hints, its fault word): the suite may run
+    under a switch that reroutes that very part (tools/env_matrix.sh); such a test pins the default routes first."""
+    for sw in ROUTE_SWITCHES:
+        monkeypatch.delenv(sw, raising=False)
+    return monkeypatch

@@ -340,6 +340,7 @@ def test_constant_prefix_hints_change_nothing(monkeypatch):
     tensor; the spectra must be bit-identical with and without them, a descending k grid must get no
     hints, and redefining the tensor by hand must drop them."""
     import hmvec_amd as hm
+    monkeypatch.delenv("HMG_NO_HINTS", raising=False)      # (the suite may run under the switch: tools/env_matrix.sh)
     zs = np.array([0.2, 1.0, 2.5])
     ms = np.geomspace(1e10, 1e16, 96)
     ks = np.geomspace(1e-4, 50, 512)
@@ -437,7 +438,7 @@ def test_compile_time_plan_equals_run_time_plan(monkeypatch):
 
 
 @pytest.mark.parametrize("nk,klo,khi", [(301, 0.5, 8.0), (64, 1e-4, 1e-2), (130, 40.0, 900.0), (257, 1e-3, 3000.0)])
-def test_left_fill_prefix_of_every_length(nk, klo, khi):
+def test_left_fill_prefix_of_every_length(default_routes, nk, klo, khi):
     """The fused profile kernel finds the end of np.interp's left-fill prefix of a row by a search and writes the
     prefix as a plain fill: rows whose targets all lie below the first FFT mode (prefix = the whole row), rows with
     none below it, odd row lengths (every other row starts off a 16-byte boundary) and targets beyond the last mode."""

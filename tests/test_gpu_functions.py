@@ -178,6 +178,8 @@ def test_table_route_runs_the_row_kernels_of_the_builtin_families(nxs, xmax, mon
     import ctypes as C
     import hmvec_amd as hm
     from hmvec_amd import _native as nat
+    for sw in ("HMG_FUSED_FFT", "HMG_PRUNED_FFT", "HMG_FUSED_GENERIC"):     # (the suite may run under a route switch)
+        monkeypatch.delenv(sw, raising=False)
     nz, nm, nk = 2, 12, 150
     xs = np.linspace(0.0, xmax, nxs + 1)[1:]
     step = (xs[-1] - xs[0]) / nxs
