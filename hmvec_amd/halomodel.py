@@ -19,7 +19,7 @@ import numpy as np
 import scipy.constants as constants
 
 from . import _native as nat
-from .cosmology import Cosmology, sigma2_kgrid, sigma2_weights
+from .cosmology import Cosmology, _is_shared_product, sigma2_kgrid, sigma2_weights
 from .params import battaglia_defaults, default_params
 from .quadrature import gradient_is_uniform, simpson_weights, trapz_weights
 from .functions import FN_BG_INTEGRAND, FN_ST_FSIGMA, FN_TINKER_FSIGMA, fn2d, ngal_from_mthresh, trapz_lastaxis
@@ -439,12 +439,13 @@ class HaloModel(Cosmology):
             elif self.accuracy == "medium":
                 self.sPzk = self.P_lin(kq, self.zs)
             else:
-                self.sPzk = self.P_lin_approx(kq, self.zs)
+                self.sPzk = self._P_lin_approx_shared(kq, self.zs)
             wq = sigma2_weights(kq)
             # P(k',z) is an input of the path: uploaded and laid out once as the contraction reads it - once per
             # MODEL, or once per host array when the provider hands out the same read-only array again (the analytic
             # provider does for a repeated cosmology: Cosmology.P_lin_approx), together with the grid and its weights
-            shared = ctx.shared.get(id(self.sPzk)) if not self.sPzk.flags.writeable else None
+            owned = _is_shared_product(self.sPzk)       # (the provider's own cached product: nothing modifies it)
+            shared = ctx.shared.get(id(self.sPzk)) if owned else None
             if shared is None or shared[0] is not self.sPzk:
                 d_sP = ctx.upload(self.sPzk)
                 n = C.c_size_t()
@@ -452,7 +453,7 @@ class HaloModel(Cosmology):
                 d_PT = ctx.empty((n.value,))
                 ctx.call("hmg_sigma2_prepare", nz, kq.size, d_sP.ptr, d_PT.ptr)
                 shared = (self.sPzk, d_PT, ctx.upload(kq), ctx.upload(wq))
-                if not self.sPzk.flags.writeable:
+                if owned:
                     if len(ctx.shared) >= 4:
                         ctx.flush()           # (queued stages of other models may hold addresses of an evicted entry)
                         ctx.shared.clear()

@@ -99,8 +99,16 @@ def test_provider_caches_return_what_a_fresh_evaluation_returns():
         for n, c in (("a", ca), ("b", cb)):
             for g, k in (("q", kq), ("k", ks)):
                 assert np.array_equal(c.Tk(k), want[(n, g)][0]) and np.array_equal(c.P_lin_approx(k, zs), want[(n, g)][1])
-    first = ca.P_lin_approx(kq, zs)
-    assert ca.P_lin_approx(kq, zs) is first and not first.flags.writeable     # the shared product itself, read-only
+    first = ca._P_lin_approx_shared(kq, zs)
+    assert ca._P_lin_approx_shared(kq, zs) is first and not first.flags.writeable   # the shared product itself, read-only
+    pub = ca.P_lin_approx(kq, zs)                                                # the public call: the caller's own array,
+    assert pub is not first and pub.flags.writeable and np.array_equal(pub, first)   # writable like the reference's
+    pub *= 2.0
+    assert np.array_equal(ca.P_lin_approx(kq, zs), first)                        # ... and the cache is out of its reach
+    tk_pub = ca.Tk(kq)
+    assert tk_pub.flags.writeable and tk_pub is not ca.Tk(kq)
+    tk_pub[:] = 0.0
+    assert np.array_equal(ca.Tk(kq), want[("a", "q")][0])
     assert ca.P_lin_approx(ks, zs) is not ca.P_lin_approx(ks, zs)               # a user's grid: a fresh array every time
     assert not np.array_equal(ca.P_lin_approx(kq, zs + 0.1), first)             # other redshifts: another entry
     k2 = ks.copy()
@@ -109,6 +117,32 @@ def test_provider_caches_return_what_a_fresh_evaluation_returns():
     k2[10] *= 1.5                                        # the same OBJECT, ONE element changed in place: another grid
     t2 = ca.Tk(k2)
     assert not np.array_equal(t1, t2) and np.array_equal(t2, ca._Tk_eval(k2, "eisenhu_osc"))
+
+
+def test_a_read_only_view_of_a_writable_grid_is_keyed_by_its_contents():
+    """`not ks.flags.writeable` does not mean the contents cannot change - a read-only VIEW follows
+    its writable base, and a flag can be toggled.  Foreign arrays are keyed by their bytes whatever their flag; only the
+    grid objects this module made itself (sigma2_kgrid) are trusted by identity."""
+    from hmvec_amd import cosmology as cm
+    cm._TK_CACHE.clear(); cm._PLIN_CACHE.clear()
+    c = Cosmology(merged_params({}), accuracy="low", engine="analytic")
+    zs = np.array([0.0, 1.0])
+    base = np.geomspace(1e-4, 50, 257)
+    view = base.view()
+    view.setflags(write=False)
+    t1, p1 = c.Tk(view).copy(), c.P_lin_approx(view, zs).copy()
+    base[100:] *= 1.25                                   # the view's contents change under the cache
+    t2, p2 = c.Tk(view), c.P_lin_approx(view, zs)
+    assert np.array_equal(t2, c._Tk_eval(view, "eisenhu_osc")) and not np.array_equal(t1, t2)
+    assert not np.array_equal(p1, p2) and np.array_equal(p2[:, :100], p1[:, :100])
+    own = np.geomspace(1e-4, 50, 129)                    # an owner whose flag is toggled around an in-place change
+    own.setflags(write=False)
+    t3 = c.Tk(own).copy()
+    own.setflags(write=True); own *= 1.1; own.setflags(write=False)
+    assert np.array_equal(c.Tk(own), c._Tk_eval(own, "eisenhu_osc")) and not np.array_equal(c.Tk(own), t3)
+    kq = cm.sigma2_kgrid(1e-4, 2e3, 500)                 # the module's own grid: by identity, shared, read-only
+    assert cm._grid_identity(kq) is kq and isinstance(cm._grid_identity(view), tuple)
+    assert not cm._is_shared_product(p2) and cm._is_shared_product(c._P_lin_approx_shared(kq, zs))
 
 
 def test_background_distances_consistent():
