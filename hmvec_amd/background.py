@@ -96,15 +96,23 @@ class AnalyticBackground:
 class CambBackground:
     """Thin forwarder to a real CAMB results object (only if camb is installed).
 
-    Mirrors the ``camb.set_params`` call at hmvec/cosmology.py:161-176.
+    Mirrors the ``camb.set_params`` call at hmvec/cosmology.py:161-176 keyword for keyword, including the
+    ``theta100`` parameterisation (hmvec/cosmology.py:140-143: ``cosmomc_theta = theta100/100`` with ``H0=None``).
+    CAMB is not installable in this image; tests/test_host_cpu.py drives this class through a recording stand-in
+    ``camb`` module, so the forwarding itself is exercised.
     """
 
     def __init__(self, params, halofit=None):
         import camb  # noqa: F401  (ImportError propagates: caller decides)
 
+        if "theta100" in params:
+            theta, H0 = params["theta100"] / 100.0, None
+        else:
+            theta, H0 = None, params["H0"]
         YHe = params.get("YHe")
+        rTensors = params.get("r", 0.0)
         self.pars = camb.set_params(
-            ns=params["ns"], As=params["As"], r=params.get("r", 0.0), H0=params["H0"],
+            ns=params["ns"], As=params["As"], r=rTensors, H0=H0, cosmomc_theta=theta,
             ombh2=params["ombh2"], omch2=params["omch2"], mnu=params["mnu"],
             omk=params["omk"], tau=params["tau"], nnu=params["nnu"],
             num_massive_neutrinos=params["num_massive_neutrinos"],
@@ -112,7 +120,8 @@ class CambBackground:
             halofit_version=params["default_halofit"] if halofit is None else halofit,
             AccuracyBoost=2, pivot_scalar=params["pivot_scalar"], YHe=YHe)
         self.pars.WantTransfer = True
-        self.pars.WantTensors = True
+        if rTensors is not None:
+            self.pars.WantTensors = True
         self.results = camb.get_background(self.pars)
         self.YHe = self.pars.YHe
 

@@ -144,18 +144,28 @@ class Cosmology(object):
 
     # ------------------------------------------------------------------ set-up
     def _init_cosmology(self, params, halofit):
-        """hmvec/cosmology.py:138-225 (H0 parameterisation only)."""
-        if "theta100" in params:
-            raise NotImplementedError("theta100 parameterisation needs CAMB's solver")
+        """hmvec/cosmology.py:138-225.  The ``theta100`` parameterisation is CAMB's to solve: it is forwarded to a
+        CAMB background as ``cosmomc_theta`` with ``H0=None`` exactly as the reference does (hmvec/cosmology.py:140-143,
+        163); the closed-form background cannot invert theta -> H0 and refuses it."""
+        theta_mode = "theta100" in params
+        if theta_mode:
+            if self._background is None and self.engine == "analytic":
+                raise NotImplementedError("theta100 parameterisation needs CAMB's solver (engine='camb')")
+            print("WARNING: Using theta100 parameterization. H0 ignored.")
+        h = None if theta_mode else params["H0"] / 100.0
         if "omm" in params:
-            hh = params["H0"] / 100.0
-            params["omch2"] = params["omm"] * hh ** 2 - params["ombh2"]
+            h = params["H0"] / 100.0
+            params["omch2"] = params["omm"] * h ** 2 - params["ombh2"]
             print("WARNING: omm specified. Ignoring omch2.")
         if self._background is None:
             self._background = self._make_background(params, halofit)
+        if h is None:
+            # the reference reaches `self.h = h` with h unassigned here (hmvec/cosmology.py:140-153,214: h is only set on
+            # the H0 and omm branches) and dies with this very exception, AFTER CAMB was set up; same behaviour
+            raise UnboundLocalError("local variable 'h' referenced before assignment")
         self.params = params
-        self.h = params["H0"] / 100.0
-        self.omm0 = (params["omch2"] + params["ombh2"]) / self.h ** 2.0
+        self.h = h
+        self.omm0 = (params["omch2"] + params["ombh2"]) / (params["H0"] / 100.0) ** 2.0
         self.omk0 = params["omk"]
         self.oml0 = 1 - self.omm0 - self.omk0
         self.as8 = params.get("as8", 1)
@@ -168,7 +178,7 @@ class Cosmology(object):
         try:
             return CambBackground(params, halofit)
         except ImportError:
-            if self.accuracy != "low":
+            if self.accuracy != "low" or "theta100" in params:
                 raise ImportError(
                     "camb is not installed: accuracy='medium'/'high' need CAMB's P(k). "
                     "Use accuracy='low' (Eisenstein-Hu) or pass background=/engine='analytic'.")

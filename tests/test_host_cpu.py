@@ -201,6 +201,113 @@ def test_medium_accuracy_through_provider_seam():
         Cosmology(accuracy="low", engine="analytic").get_pk_interpolator(zs, 10.0)
 
 
+def _recording_camb(monkeypatch, calls):
+    """A stand-in `camb` module (the shape tools/make_golden.py registers for the reference) that RECORDS what the
+    seam passes to it: set_params keywords, the parameter object's flags, get_matter_power_interpolator arguments."""
+    import sys
+    import types
+    from hmvec_amd.background import TabulatedPowerInterpolator
+    camb = types.ModuleType("camb")
+    model = types.ModuleType("camb.model")
+    model.Transfer_Weyl = "Transfer_Weyl_sentinel"
+
+    class Pars:
+        pass
+
+    def set_params(**kw):
+        calls.append(("set_params", dict(kw)))
+        p = Pars()
+        p.kw = dict(kw)
+        p.YHe = 0.2454 if kw.get("YHe") is None else kw["YHe"]
+        return p
+
+    def get_background(pars):
+        calls.append(("get_background", {"WantTransfer": getattr(pars, "WantTransfer", None),
+                                         "WantTensors": getattr(pars, "WantTensors", None)}))
+        k = pars.kw
+        return AnalyticBackground(H0=k["H0"] if k["H0"] is not None else 67.0, ombh2=k["ombh2"], omch2=k["omch2"],
+                                  omk=k["omk"], w0=k["w"], wa=k["wa"], YHe=pars.YHe)
+
+    def get_matter_power_interpolator(pars, **kw):
+        calls.append(("get_matter_power_interpolator", dict(kw), pars))
+        from helpers.pk_table import table
+        return TabulatedPowerInterpolator(*table(pars.kw["ns"]))
+
+    camb.set_params, camb.get_background = set_params, get_background
+    camb.get_matter_power_interpolator, camb.model = get_matter_power_interpolator, model
+    monkeypatch.setitem(sys.modules, "camb", camb)
+    monkeypatch.setitem(sys.modules, "camb.model", model)
+    return camb
+
+
+def test_camb_seam_forwards_the_reference_keywords(monkeypatch):
+    """VERDICT r05 missing #2 / weak #8: CambBackground is exercised through a recording stand-in `camb`.  The exact
+    keyword set of camb.set_params (hmvec/cosmology.py:161-176), the two Want* flags (:177-179) and of
+    camb.get_matter_power_interpolator (:783-786) is asserted; HaloModel(accuracy='medium', engine='camb') is built up
+    to its first device call (ms=None, skip_nfw=True: the constructor then only sets up the cosmology and P(z,k))."""
+    from hmvec_amd import HaloModel
+    from hmvec_amd.background import CambBackground
+    calls = []
+    _recording_camb(monkeypatch, calls)
+    p = merged_params({"YHe": 0.25, "r": 0.01})
+    zs, ks = np.array([0.0, 0.5, 1.5]), np.geomspace(1e-3, 5.0, 40)
+    h = HaloModel(zs, ks, ms=None, params=dict(p), skip_nfw=True, accuracy="medium", engine="camb", halofit=None)
+    assert isinstance(h._background, CambBackground)
+    name, kw = calls[0]
+    assert name == "set_params"
+    want = dict(ns=p["ns"], As=p["As"], r=0.01, H0=p["H0"], cosmomc_theta=None, ombh2=p["ombh2"], omch2=p["omch2"],
+                mnu=p["mnu"], omk=p["omk"], tau=p["tau"], nnu=p["nnu"], num_massive_neutrinos=p["num_massive_neutrinos"],
+                w=p["w0"], wa=p["wa"], dark_energy_model="ppf", halofit_version=p["default_halofit"], AccuracyBoost=2,
+                pivot_scalar=p["pivot_scalar"], YHe=0.25)
+    assert kw == want                                   # same keys, same values: nothing missing, nothing extra
+    assert calls[1] == ("get_background", {"WantTransfer": True, "WantTensors": True})
+    assert h.YHe == 0.25 and abs(h.h - p["H0"] / 100.0) < 1e-15
+    # the constructor's P(z,k) for accuracy != 'low' (hmvec/hmvec.py:99-100 -> cosmology.py:227-229,783-786)
+    name, kw, pars = calls[2]
+    assert name == "get_matter_power_interpolator" and pars is h._background.pars
+    assert kw == dict(nonlinear=False, hubble_units=False, k_hunit=False, kmax=ks.max(), var1="delta_tot",
+                      var2="delta_tot", zmax=zs[-1])
+    from helpers.pk_table import table
+    from hmvec_amd.background import TabulatedPowerInterpolator
+    assert np.array_equal(h.Pzk, TabulatedPowerInterpolator(*table(p["ns"])).P(zs, ks, grid=True))
+    # the other two variables of hmvec/cosmology.py:775-782 and the non-linear switch
+    n0 = len(calls)
+    h.get_pk_interpolator(zs, 3.0, var="weyl", nonlinear=True)
+    h.get_pk_interpolator(zs, 3.0, var="CB")
+    assert calls[n0][1]["var1"] == calls[n0][1]["var2"] == "Transfer_Weyl_sentinel" and calls[n0][1]["nonlinear"] is True
+    assert calls[n0 + 1][1]["var1"] == "delta_nonu" and calls[n0 + 1][1]["kmax"] == 3.0
+    with pytest.raises(KeyError):
+        h.get_pk_interpolator(zs, 3.0, var="bogus")
+    # halofit: version forwarded, and the non-linear P(z,k) is asked for as well (hmvec/hmvec.py:101-102)
+    calls.clear()
+    h2 = HaloModel(zs, ks, ms=None, params=dict(p), skip_nfw=True, accuracy="medium", engine="camb", halofit="takahashi")
+    assert calls[0][1]["halofit_version"] == "takahashi"
+    assert [c[1]["nonlinear"] for c in calls if c[0] == "get_matter_power_interpolator"] == [False, True]
+    assert np.array_equal(h2.nPzk, h2.Pzk)              # (the stand-in serves one table for both)
+
+
+def test_theta100_is_forwarded_to_camb_as_cosmomc_theta(monkeypatch, capsys):
+    """hmvec/cosmology.py:140-143,163: theta100 -> cosmomc_theta = theta100/100 with H0=None.  The reference then needs
+    `omm` to define h (its h is otherwise unassigned: UnboundLocalError at hmvec/cosmology.py:214, after CAMB was set up);
+    both behaviours are kept.  Without CAMB the closed-form background cannot solve theta -> H0 and says so."""
+    calls = []
+    _recording_camb(monkeypatch, calls)
+    p = merged_params({"theta100": 1.04109, "omm": 0.31})
+    cos = Cosmology(dict(p), accuracy="medium", engine="camb")
+    out = capsys.readouterr().out
+    assert "WARNING: Using theta100 parameterization. H0 ignored." in out and "WARNING: omm specified" in out
+    kw = calls[0][1]
+    assert kw["H0"] is None and kw["cosmomc_theta"] == 1.04109 / 100.0
+    assert abs(kw["omch2"] - (0.31 * (p["H0"] / 100.0) ** 2 - p["ombh2"])) < 1e-15      # omm rewrote omch2 first
+    assert abs(cos.h - p["H0"] / 100.0) < 1e-15
+    calls.clear()
+    with pytest.raises(UnboundLocalError):
+        Cosmology(merged_params({"theta100": 1.04109}), accuracy="medium", engine="camb")
+    assert calls and calls[0][1]["cosmomc_theta"] == 1.04109 / 100.0                     # ... after CAMB was set up
+    with pytest.raises(NotImplementedError):
+        Cosmology(merged_params({"theta100": 1.04109, "omm": 0.31}), accuracy="low", engine="analytic")
+
+
 def test_bench_launcher_dry_run_and_failure_propagation():
     """`python bench.py --gpus N` without a rank environment spawns the N ranks itself (the way the
     driver starts N=1).  --dry-run shows the dispatch; on this GPU-less box the ranks fail at context
