@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 7
+ABI_VERSION = 8
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -73,7 +73,8 @@ class RowsPart(C.Structure):
                 ("gamma", C.c_double), ("alpha_const", C.c_double), ("amp_prefactor", C.c_double),
                 ("post_prefactor", C.c_double), ("d_amp", C.c_void_p), ("d_xc", C.c_void_p),
                 ("d_alpha", C.c_void_p), ("d_expo", C.c_void_p), ("d_cmax", C.c_void_p),
-                ("d_rscale", C.c_void_p), ("d_post", C.c_void_p)]
+                ("d_rscale", C.c_void_p), ("d_post", C.c_void_p),
+                ("d_ks", C.c_void_p), ("d_kts", C.c_void_p), ("nk", C.c_int), ("fft_m", C.c_int), ("d_rowsc", C.c_void_p)]
 
 
 class NfwPart(C.Structure):
@@ -89,7 +90,8 @@ class ProfileFftPart(C.Structure):
                 ("amp_const", C.c_double), ("xc_const", C.c_double), ("alpha_const", C.c_double),
                 ("expo_const", C.c_double), ("gamma", C.c_double), ("d_cmax", C.c_void_p), ("d_rss", C.c_void_p),
                 ("d_zs", C.c_void_p), ("d_ks", C.c_void_p), ("do_mass_norm", C.c_int), ("d_post", C.c_void_p),
-                ("d_out", C.c_void_p), ("d_nconst", C.c_void_p), ("d_cconst", C.c_void_p), ("d_logxs", C.c_void_p)]
+                ("d_out", C.c_void_p), ("d_nconst", C.c_void_p), ("d_cconst", C.c_void_p), ("d_logxs", C.c_void_p),
+                ("d_rowsc", C.c_void_p)]
 
 
 class PowerBatchDesc(C.Structure):
@@ -109,6 +111,7 @@ TRACER_MATTER, TRACER_HOD, TRACER_PRESSURE = 0, 1, 2
 KERNEL_POWER, KERNEL_NFW, KERNEL_PROFILE_FFT = 0, 1, 2
 EVENT_SLOTS = 4096
 NFW_SERIES_STRIDE = 36     # HMG_NFW_SERIES_STRIDE
+ROWSC_STRIDE = 8            # HMG_ROWSC_STRIDE
 
 _I, _D, _P, _Z = C.c_int, C.c_double, C.c_void_p, C.c_size_t
 # name -> argtypes (restype is int for all but hmg_last_error); mirrors include/hmgrid.h

@@ -825,7 +825,34 @@ __global__ __launch_bounds__(256, HMG_NFW_OCC) void nfw_kernel(const SiciTable* 
 struct RowFit { double f[9]; };
 struct RowOut {
     double *amp, *xc, *alpha, *expo, *cmax, *rscale, *post;
+    // optional row scalars of the profile transform that will read these rows (hmg_rows_part, ABI 8)
+    double* rowsc;
+    const double *ks, *kts;
+    int nk, M;
 };
+// The output-side scalars of one profile row (hmvec/fft.py:96-107), the SAME expressions profile_fused_row evaluates
+// when it has to work them out itself: isc = 1/(r (1+z)) (kout_j = kt_j isc), k_lo = kt_1 isc, k_hi = kt_M isc, 1/k_lo,
+// 1/kt_1, jn = modes the target grid can reach, nleft = targets below k_lo (ks ascending: a bisection here, a 64-way
+// search there - the same count).
+__device__ __forceinline__ void rowscal_store(const RowOut& O, int idx, double rscale, double z1) {
+    if (!O.rowsc) return;
+    const double isc0 = 1.0 / (rscale * z1);
+    const double kt1 = O.kts[1];
+    const double klo0 = kt1 * isc0;
+    const double idk0 = 1.0 / klo0;
+    int jn0 = O.M;
+    const double tmax = O.ks[O.nk - 1] * idk0;
+    if (tmax < (double)(O.M - 4)) jn0 = (int)tmax + 3;
+    int lo = 0, hi = O.nk;                     // ks[i] < k_lo for i < lo, ks[i] >= k_lo for i >= hi
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (O.ks[mid] < klo0) lo = mid + 1; else hi = mid;
+    }
+    double* __restrict__ r = O.rowsc + (size_t)idx * HMG_ROWSC_STRIDE;
+    r[0] = isc0; r[1] = klo0; r[2] = O.kts[O.M] * isc0; r[3] = idk0; r[4] = 1.0 / kt1;
+    r[5] = __hiloint2double(jn0, lo);
+    r[6] = 0.0; r[7] = 0.0;
+}
 __device__ __forceinline__ void rowparams_body(int kind, int idx, double M, double R, double rv, double z1,
                                                double rhoc, double hz, const RowFit& F, double gamma,
                                                double alpha_const, double pref, double post_pref,
@@ -846,6 +873,7 @@ __device__ __forceinline__ void rowparams_body(int kind, int idx, double M, doub
         O.rscale[idx] = rg;
         O.cmax[idx] = rv / rg;
         if (O.post) O.post[idx] = 1.0;
+        rowscal_store(O, idx, rg, z1);
     } else {
         // eFrac (Ob/Om) 200 M G rho_c / (2 R200) P0 (x/xc)^g (1+(x/xc)^alpha)^(-beta),  x = r/R200c
         O.amp[idx] = pref * M * rhoc / (2.0 * R) * X0;
@@ -855,6 +883,7 @@ __device__ __forceinline__ void rowparams_body(int kind, int idx, double M, doub
         O.rscale[idx] = R;
         O.cmax[idx] = rv / R;
         if (O.post) O.post[idx] = post_pref * ((R * R * R) * ((z1 * z1) / hz));
+        rowscal_store(O, idx, R, z1);
     }
 }
 
@@ -1217,7 +1246,10 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // the number of lanes that see it below k_lo is the number of segments that lie in the prefix entirely, and the
     // next segment holds the boundary (two dependent loads for nk <= 4096).  Phase D then fills [0, nleft)
     // without loading or testing a wavenumber.
-    if (threadIdx.x >= NT - 64) {
+    // (with A.rowsc - the grouped passes of the facade - the launch that computed the rows' length scales left these
+    // numbers per row: they arrive by scalar loads and no wavefront of this workgroup divides or searches)
+    const double* __restrict__ rsc = A.rowsc ? A.rowsc + (size_t)row * HMG_ROWSC_STRIDE : nullptr;
+    if (!rsc && threadIdx.x >= NT - 64) {
         const int lane = threadIdx.x & 63;
         const double isc0 = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));      // kout_j = kts[j] * isc
         const double klo0 = A.kts[1] * isc0;
@@ -1321,9 +1353,9 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) tot += red[w];
         const double mnorm = A.do_norm ? tot : 1.0;
-        if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
+        if (threadIdx.x == 0) red[24] = -A.step / mnorm * (rsc ? rsc[4] : red[23]);
     }
-    const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
+    const int jn = rsc ? __double2hiint(rsc[5]) : __builtin_amdgcn_readfirstlane(*s_jn);
     FSTAMP(1);
 #ifdef HMG_FR_STAMP
     if (fslot >= 0 && threadIdx.x == 0) g_fstamps[fslot * 16 + 13] = jn;
@@ -1414,14 +1446,14 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid:
     // bracket j = floor(k/k_lo), weight k/k_lo - j (one FMA), two LDS reads.  The left fill is a
     // plain splat (63 % of the Battaglia tensor at Config 3).
-    const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
+    const double k_lo = rsc ? rsc[1] : red[20], k_hi = rsc ? rsc[2] : red[21], inv_dk = rsc ? rsc[3] : red[22];
     const double pf = A.post ? A.post[row] : 1.0;
     const double u1 = u[0];
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
     // with the hint arrays the left fill [0, nleft) is a plain fill in 16-byte stores (no wavenumber is loaded or
     // tested) and the interpolation starts at the 64-aligned index below nleft, so that its stores stay on whole
     // 512-byte wavefront segments; without them (ks in any order) every target is tested
-    const int nleft = A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0;
+    const int nleft = rsc ? __double2loint(rsc[5]) : (A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0);
     if (nleft > 0) {
         typedef double v2d __attribute__((ext_vector_type(2)));
         const double c = u1 * pf;
@@ -3831,6 +3863,8 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             A.nconst = nconst; A.cconst = cconst;
             A.logx = logxs;
             A.rho_tab = rho_tab; A.rho_shared = rho_shared;
+            // the row scalars a rows part left for exactly this transform (they carry the left-fill count: hints required)
+            A.rowsc = (p.d_rowsc && nconst) ? p.d_rowsc : nullptr;
             int stop = -1;
             if (bracket_open(c, HMG_KERNEL_PROFILE_FFT, &stop)) return 1;
             if (rho_tab) {      // table builds: the nxs = 5000 plan and two run-time-plan shapes cover every one-row length
@@ -4284,6 +4318,10 @@ static int rows_setup(int nz, int nm, const hmg_rows_part* rows, RowsArgs* out) 
     Rw.gamma = rows->gamma; Rw.alpha_const = rows->alpha_const; Rw.pref = rows->amp_prefactor;
     Rw.post_pref = rows->post_prefactor;
     Rw.O = RowOut{rows->d_amp, rows->d_xc, rows->d_alpha, rows->d_expo, rows->d_cmax, rows->d_rscale, rows->d_post};
+    if (rows->d_rowsc) {
+        REQUIRE(rows->d_ks && rows->d_kts && rows->nk > 0 && rows->fft_m >= 2, "row scalars need d_ks, d_kts, nk and fft_m");
+        Rw.O.rowsc = rows->d_rowsc; Rw.O.ks = rows->d_ks; Rw.O.kts = rows->d_kts; Rw.O.nk = rows->nk; Rw.O.M = rows->fft_m;
+    }
     *out = Rw;
     return 0;
 }

@@ -58,6 +58,9 @@ struct FusedArgs {
     // from a table instead of the family - rho_tab[n] shared by every row, or rho_tab[row nxs + n]
     const double* rho_tab;
     int rho_shared;
+    // optional: the output-side scalars of every row ([rows][HMG_ROWSC_STRIDE], include/hmgrid.h: hmg_rows_part), left by
+    // the launch that computed the rows' length scales; nullptr: one wavefront of the row's workgroup works them out
+    const double* rowsc;
 };
 
 // amp * t^gamma * (1 + t^alpha)^(-expo), t = x/xc, through exp/log (one log shared by the two

@@ -577,7 +577,7 @@ class HaloModel(Cosmology):
             self._dcache[key] = (d_xs, ctx.upload(kts), float(step), d_lx)
         return self._dcache[key]
 
-    def _profile_fft(self, key, nxs, xmax, rowp, consts, gamma, d_cmax, d_rss, do_mass_norm, d_post=None):
+    def _profile_fft(self, key, nxs, xmax, rowp, consts, gamma, d_cmax, d_rss, do_mass_norm, d_post=None, d_rowsc=None):
         """One hmg_profile_fft launch; returns (tensor, hint).  The hint - how many leading target
         wavenumbers of each row lie below the row's first FFT mode, and the value np.interp's left
         fill gives them all - lets the batched mass integrals skip those parts of the tensor.  It
@@ -601,14 +601,18 @@ class HaloModel(Cosmology):
                 nat.ptr(d_post), out.ptr, nat.ptr(hint[0] if hint else None), nat.ptr(hint[1] if hint else None),
                 d_lx.ptr)
         if self._groups:
-            self._queue("fft", nat.ProfileFftPart(*args))
+            # (the row scalars only travel with the hint arrays: they carry the left-fill count, which needs ks ascending)
+            self._queue("fft", nat.ProfileFftPart(*args, nat.ptr(d_rowsc if hint else None)))
         else:
             ctx.call("hmg_profile_support_epoch", getattr(self, "_epoch", 0))
             ctx.call("hmg_profile_fft", nz, nm, nk, *args)
             ctx.call("hmg_profile_support_epoch", 0)
         return out, hint
 
-    def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref):
+    def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref, nxs=None, xmax=None):
+        """Row parameters of a Battaglia family; returns (outs, d_rowsc): with a radial grid (nxs, xmax) and an ascending
+        k grid the queued stage also leaves the output-side scalars of every row for the transform (hmg_rows_part,
+        ABI 8), d_rowsc is then the buffer to hand to _profile_fft, else None."""
         ctx = self._ctx()
         nz, nm = self._nz, self._nm
         outs = [self._buf((key, "rowp", i), (nz, nm)) for i in range(7)]
@@ -623,17 +627,26 @@ class HaloModel(Cosmology):
                      C.byref(fit), float(gamma), float(alpha_const), float(pref), float(post_pref),
                      m2.ptr, r2.ptr, *[o.ptr for o in outs])
             self._m200c_valid = True
-            return outs
+            return outs, None
         m200c, r200c = self._m200c()
         if self._groups:
+            d_rowsc, extra = None, (None, None, 0, 0, None)
+            if nxs is not None and nxs % 2 == 0 and os.environ.get("HMG_NO_ROWSC", "0") != "1":
+                if "ks_ascending" not in self._dcache:
+                    self._dcache["ks_ascending"] = (bool(np.all(np.diff(self.ks) > 0))
+                                                    and os.environ.get("HMG_NO_HINTS", "0") != "1")
+                if self._dcache["ks_ascending"]:
+                    d_kts = self._fft_grids(xmax, nxs)[1]
+                    d_rowsc = self._buf((key, "rowsc"), (nz, nm, nat.ROWSC_STRIDE))
+                    extra = (self._d_ks().ptr, d_kts.ptr, self._nk, int(nxs) // 2, d_rowsc.ptr)
             self._queue("rows", nat.RowsPart(kind, m200c.ptr, r200c.ptr, self._d_rvir.ptr, self._d_zs().ptr, d_rhoc.ptr,
                                              d_hz.ptr, fit, float(gamma), float(alpha_const), float(pref),
-                                             float(post_pref), *[o.ptr for o in outs]))
-            return outs
+                                             float(post_pref), *[o.ptr for o in outs], *extra))
+            return outs, d_rowsc
         ctx.call("hmg_profile_rowparams", kind, nz, nm, m200c.ptr, r200c.ptr, self._d_rvir.ptr,
                  self._d_zs().ptr, d_rhoc.ptr, d_hz.ptr, C.byref(fit), float(gamma), float(alpha_const),
                  float(pref), float(post_pref), *[o.ptr for o in outs])
-        return outs
+        return outs, None
 
     def add_battaglia_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
                               ignore_existing=False):
@@ -659,10 +672,10 @@ class HaloModel(Cosmology):
         fit9 = [pparams[a + b] for a in ("rho0_", "alpha_", "beta_") for b in ("A0", "alpham", "alphaz")]
         key = ("uk", name)
         self._main()
-        amp, xc, alpha, expo, cmax, rscale, _post = self._battaglia_rowparams(
-            key, nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0)
+        (amp, xc, alpha, expo, cmax, rscale, _post), rowsc = self._battaglia_rowparams(
+            key, nat.PROF_BATTAGLIA_GAS, fit9, gamma, 0.0, omb / self.omm0, 0.0, nxs=nxs, xmax=xmax)
         out, hint = self._profile_fft(key, nxs, xmax, (amp, None, alpha, expo), (0.0, 1.0, 0.0, 0.0), gamma,
-                                      cmax, rscale, True)
+                                      cmax, rscale, True, d_rowsc=rowsc)
         self.uk_profiles.set_dev(name, out, hint)
 
     def add_battaglia_pres_profile(self, name, family=None, param_override=None, nxs=None, xmax=None,
@@ -696,10 +709,10 @@ class HaloModel(Cosmology):
         post_pref = 4 * np.pi * (sigmaT / (mElect * constants.c ** 2))
         key = ("pk", name)
         self._main()
-        amp, xc, _alpha, expo, cmax, rscale, post = self._battaglia_rowparams(
-            key, nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref)
+        (amp, xc, _alpha, expo, cmax, rscale, post), rowsc = self._battaglia_rowparams(
+            key, nat.PROF_BATTAGLIA_PRES, fit9, gamma, alpha, pref, post_pref, nxs=nxs, xmax=xmax)
         out, hint = self._profile_fft(key, nxs, xmax, (amp, xc, None, expo), (0.0, 0.0, alpha, 0.0), gamma,
-                                      cmax, rscale, False, d_post=post)
+                                      cmax, rscale, False, d_post=post, d_rowsc=rowsc)
         self.pk_profiles.set_dev(name, out, hint)
 
     def add_nfw_profile(self, name, numeric=False, nxs=None, xmax=None, ignore_existing=False):

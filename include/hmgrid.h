@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMG_ABI_VERSION 7
+#define HMG_ABI_VERSION 8
 
 typedef struct hmg_ctx hmg_ctx;
 
@@ -386,7 +386,17 @@ typedef struct {   /* hmg_profile_rowparams's arguments */
     const double *d_m200c, *d_r200c, *d_rvir, *d_zs, *d_rhocz, *d_hz;
     double fit[9], gamma, alpha_const, amp_prefactor, post_prefactor;
     double *d_amp, *d_xc, *d_alpha, *d_expo, *d_cmax, *d_rscale, *d_post;
+    /* ABI 8, optional (d_rowsc NULL: none): the OUTPUT-side scalars of every profile row, worked out here once per row by
+     * the thread that has just computed the row's length scale instead of by one wavefront of every row workgroup of
+     * hmg_profile_fft (hmvec/fft.py:96-107: k_out = kt / (r_s (1+z)), np.interp's left fill below kt_1 / (r_s (1+z))).
+     * d_rowsc [nz*nm][HMG_ROWSC_STRIDE]: 1/(rscale (1+z)), k_lo = kt_1 that, k_hi = kt_M that, 1/k_lo, 1/kt_1, and - packed
+     * in one double, high word first - the number of FFT modes the target grid can reach and the length of the left-fill
+     * prefix.  Needs d_ks ASCENDING ([nk]), d_kts ([fft_m + 1]), fft_m = nxs/2 of the transform that will read it.       */
+    const double *d_ks, *d_kts;
+    int nk, fft_m;
+    double* d_rowsc;
 } hmg_rows_part;
+#define HMG_ROWSC_STRIDE 8
 typedef struct {   /* hmg_nfw_analytic's arguments (d_nfw_series is required here) */
     const double *d_cs, *d_rs, *d_zs, *d_ks, *d_nfw_series;
     double* d_uk;
@@ -403,6 +413,7 @@ typedef struct {   /* hmg_profile_fft's arguments after nk */
     int* d_nconst;
     double* d_cconst;
     const double* d_logxs;
+    const double* d_rowsc;   /* ABI 8, optional: the row scalars an hmg_rows_part with the same d_ks, d_kts, nxs/2 left (needs the hint arrays) */
 } hmg_profile_fft_part;
 typedef struct {   /* hmg_power_batch's arguments after nk */
     int ntr;
