@@ -504,6 +504,9 @@ def main():
                          "xmax=50 with nxs=30000: examples/lensing_baryons.py:27, bin/tests.py:308)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches of every step one by one")
+    ap.add_argument("--graph", action="store_true",
+                    help="time HIP-graph replays of the step (rounds 2-5's default) instead of eager launches from the "
+                         "recorded list of native calls; the other mode is measured beside it either way")
     ap.add_argument("--lanes", action="store_true",
                     help="independent stages on separate HIP streams (concurrent graph branches)")
     ap.add_argument("--per-pair", action="store_true", help="six hmg_power launches instead of one hmg_power_batch")
@@ -593,8 +596,20 @@ def main():
     for _ in range(2):
         spec.wait_gathered(); compute(); spec.gather()
     ctx.sync()
-    use_graph = not args.no_graph and not args.stages
-    g_plain = g_brack = t_brack = None
+    # Launch mode of the timed steps.  Default since round 6: the native calls of a pass recorded ONCE (Context.trace) and
+    # re-issued eagerly per step without the Python facade (4 launches, ~0.02 ms of host time per step).  Rounds 2-5 replayed
+    # a captured HIP graph of the same launches: on ROCm 7.2 consecutive graph launches leave ~4-9 us between the last
+    # kernel of one replay and the first of the next (profiles/r06/slab4_timeline.txt), which a 0.1 ms thin-slab step
+    # feels; eager launches on one stream run back to back.  --graph times the replay instead; the other mode is
+    # measured beside the timed one either way (launch_modes in the JSON).
+    args.call_list = not args.graph and not args.no_graph and not args.stages
+    use_graph = args.graph and not args.no_graph and not args.stages
+    can_both = not args.no_graph and not args.stages
+    g_plain = g_brack = t_brack = t_plain = None
+    if args.call_list:
+        t_plain = ctx.trace(lambda: compute())
+        t_brack = ctx.trace(lambda: compute(brackets=True))
+        ctx.sync()
     events_in_graph = False
     if use_graph:
         g_plain = ctx.capture(lambda: compute())
@@ -648,8 +663,8 @@ def main():
         spec.wait_gathered()
         if use_graph and (not bracketed or events_in_graph):
             ctx.replay(g_brack if bracketed else g_plain)
-        elif use_graph and t_brack is not None:
-            ctx.run_trace(t_brack)
+        elif t_brack is not None and (use_graph or args.call_list):
+            ctx.run_trace(t_brack if bracketed else t_plain)
         else:
             compute(brackets=bracketed, stages=bracketed and args.stages)
         spec.gather()
@@ -691,6 +706,31 @@ def main():
                              "group on the communication lane (ready -> done).  In the timed loop this collective overlaps "
                              "the next pass"}
     kms = {k: (float(np.mean(v)) if v else None) for k, v in kern_ms.items()}
+
+    # ---- the other launch mode, beside the timed one (same kernels; 40 steps after 16 warm-up steps, max over ranks)
+    other_mode = None
+    if can_both:
+        if args.call_list:
+            g_other = ctx.capture(lambda: compute())
+            issue = lambda: ctx.replay(g_other)                 # noqa: E731
+            other_name = "hip-graph replay"
+        else:
+            t_other = ctx.trace(lambda: compute())
+            issue = lambda: ctx.run_trace(t_other)              # noqa: E731
+            other_name = "eager launches from a recorded call list"
+        def other_step():
+            spec.wait_gathered(); issue(); spec.gather()
+        for _ in range(16):
+            other_step()
+        comm.barrier(); ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(40):
+            other_step()
+        comm.barrier(); ctx.sync()
+        dt_o = time.perf_counter() - t1
+        dt_o = float(comm.allgather_host([dt_o]).max()) if world > 1 else dt_o
+        other_mode = {"mode": other_name, "ms_per_step": dt_o / 40 * 1e3, "steps": 40}
+    g_count = g_plain if g_plain is not None else (g_other if (can_both and args.call_list) else None)
 
     nzl, nm_, nk_, nxs = zloc.size, ms.size, ks.size, args.nxs
     B = nzl * nm_
@@ -854,7 +894,7 @@ def main():
         # ---- streamed hand-over: a double-buffered result block; pass i's copy to the host runs on the copy lane
         # under pass i+1's kernels, the host consumes pass i-1 meanwhile.  Same kernels, same numbers.
         streamed = None
-        if use_graph:
+        if can_both:
             blk2 = h.spectra_block(PAIRS, nbuf=2)
 
             def pass_into(slot):
@@ -937,7 +977,13 @@ def main():
         "value": pts * K / dt_max, "unit": "grid-points/s",
         "n_gpus": world, "rccl_ranks": rccl_ranks, "transport": "rccl" if rccl_ranks else None, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3,
         "host_issue_ms_per_step": t_issue / K * 1e3, "preconditioning_steps": PRECONDITION,
-        "launch_mode": ("hip-graph replay" if use_graph else "eager launches") + (", lanes" if args.lanes else ""),
+        "launch_mode": ("hip-graph replay" if use_graph else "eager launches from a recorded call list" if args.call_list
+                        else "eager launches") + (", lanes" if args.lanes else ""),
+        "launch_modes": {"timed": {"mode": "hip-graph replay" if use_graph else "eager launches from a recorded call list"
+                                           if args.call_list else "eager launches", "ms_per_step": dt_max / K * 1e3},
+                         "other": other_mode,
+                         "note": "same launches either way; `value` is the timed mode.  Graph replays leave a gap between "
+                                 "consecutive launches of the graph (profiles/r06/slab4_timeline.txt)"},
         "kernel_events": f"HIP events around the three large kernels on every {BRACKET_EVERY}th timed step"
                          + (" (graph event nodes)" if use_graph and events_in_graph else
                             " (eager launches from a recorded call list)" if t_brack is not None else " (eager launches)"),
@@ -968,9 +1014,9 @@ def main():
                              "survey_model, outside this block: it is not a bandwidth of this design"},
         "roofline_time_dominant": roofline_time_dominant,
         "kernels": kernels,
-        "launches_per_step": (ctx.graph_kernel_nodes(g_plain) if g_plain is not None else None),
+        "launches_per_step": (ctx.graph_kernel_nodes(g_count) if g_count is not None else None),
         "launches_per_step_source": ("kernel nodes of the captured step (hipGraphGetNodes), counted by the library at capture end"
-                                     if g_plain is not None else "not counted: eager launches (--no-graph / --stages)"),
+                                     if g_count is not None else "not counted: eager launches (--no-graph / --stages)"),
         "launch_grouping": ("front (sigma^2 contraction | halo stage | HOD occupations), rows group, profile group, "
                             "mass integrals" if grouped else "one launch per stage (HMG_NO_GROUPS=1)"),
         "kernel_source_sha16": sha, "stale_profiles_ignored": stale or None,

@@ -203,7 +203,9 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
-    for name in ("hmgrid.hip", "longgrid.hip", "longgrid.hpp", "rowdev.hpp", "sici.hpp", "ldsfft.hpp", "fastmath.hpp", "Makefile"):
+    names = ["hmgrid.hip", "longgrid.hip", "longgrid.hpp", "rowdev.hpp", "sici.hpp", "ldsfft.hpp", "fastmath.hpp", "Makefile"]
+    names += sorted(os.path.join("kernels", n) for n in os.listdir(os.path.join(csrc, "kernels")) if n.endswith(".hpp"))
+    for name in names:          # (runtime.hip / comm.hip / hmctx.hpp hold no device code: not part of the kernel identity)
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -7,15 +7,6 @@
 
 namespace hmg {
 
-// In-kernel time stamps (diagnostic builds only: -DHMG_LG_STAMP; tools/probes/long_stamps.py): thread 0 of every 29th
-// row workgroup records the shader clock at the phase boundaries of its row.
-#ifdef HMG_LG_STAMP
-__device__ long long g_stamps[4096 * 64];
-#define STAMP(k) do { if (stamp_slot >= 0 && threadIdx.x == 0) g_stamps[stamp_slot * 64 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
-
 // ---------------------------------------------------------------- K45p: long radial grids with short support
 // nxs = 30000 / 40000 - what the reference's own callers pass (examples/lensing_baryons.py:27 and bin/tests.py:308:
 // add_battaglia_profile(xmax=50, nxs=30000); hmvec/params.py:59-60: numeric NFW, nxs = 40000, xmax = 200) - do not
@@ -75,14 +66,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     // profile_fused_row.  The packed samples of the row stay in REGISTERS: thread j < LP/R0 owns the R0 inputs
     // j + t LP/R0 of butterfly j of the first pass (radix R0, sub-transform size 1: no pass twiddles), so the
     // multiplication by W_M^{rp} and the first pass of every residue's transform need no LDS read at all.
-#ifdef HMG_LG_STAMP
-    const int stamp_slot = (blockIdx.x % 29 == 0 && blockIdx.x / 29 < 4096) ? (int)(blockIdx.x / 29) : -1;
-    if (stamp_slot >= 0 && threadIdx.x < 64) g_stamps[stamp_slot * 64 + threadIdx.x] = 0;
-#endif
-    STAMP(0);
-#ifdef HMG_LG_STAMP
-    if (stamp_slot >= 0 && threadIdx.x == 0) g_stamps[stamp_slot * 64 + 60] = (long long)wall_clock64();   // 100 MHz
-#endif
     cplx* buf = reinterpret_cast<cplx*>(smem);
     double* red = smem + 4 * (size_t)LP;
     int* s_cnt = reinterpret_cast<int*>(red + 17);
@@ -160,10 +143,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                 const int j = 2 * (jb + t * nb0);
                 const double2 xv = *reinterpret_cast<const double2*>(A.xs + j);
                 double r0 = 0.0, r1 = 0.0;
-#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 64)     // timing experiment: no transcendentals in the integrand
-                if (!(fabs(xv.x) > cm)) r0 = Aamp * xv.x + AL;
-                if (!(fabs(xv.y) > cm)) r1 = Aamp * xv.y + EX;
-#else
                 if (tab) {       // a user's profile from a table (hmg_profile_fft_table): wave-uniform
                     if (!(fabs(xv.x) > cm)) r0 = tab[j];
                     if (!(fabs(xv.y) > cm)) r1 = tab[j + 1];
@@ -171,7 +150,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                     if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast((A.logx ? A.logx[j] : log_fast(xv.x)) - ln_xc, Aamp, AL, EX, A.gamma);
                     if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast((A.logx ? A.logx[j + 1] : log_fast(xv.y)) - ln_xc, Aamp, AL, EX, A.gamma);
                 }
-#endif
                 zp[b][t] = cplx{xv.x * r0, xv.y * r1};
                 if (A.do_norm && (r0 != 0.0 || r1 != 0.0)) {
                     const double xl = (j > 0) ? A.xs[j - 1] : xv.x, xr = (j + 2 < nxs) ? A.xs[j + 2] : xv.y;
@@ -193,10 +171,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         if (threadIdx.x == 0) red[24] = -A.step / mnorm * red[23];
     }
     const int jn = __builtin_amdgcn_readfirstlane(*s_jn);
-    STAMP(1);
-#ifdef HMG_LG_STAMP
-    if (stamp_slot >= 0 && threadIdx.x == 0) { g_stamps[stamp_slot * 64 + 62] = jn; g_stamps[stamp_slot * 64 + 63] = row; }
-#endif
     // ---- phase B + C: per group of residues {g, R - g}: first pass from registers, the other passes in LDS,
     // unpack into the scratch line
     double* u = G.u + (size_t)(row - G.row0) * M;
@@ -224,9 +198,7 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                 }
             }
             __syncthreads();
-            STAMP(2);
             pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, -1);
-            STAMP(3);
             {   // product with the window's transform, fused into the first pass of the second transform
                 cplx v[MAXB0][4];
 #pragma unroll
@@ -249,9 +221,7 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
                 }
                 __syncthreads();
             }
-            STAMP(4);
             pruned_passes<NT, LC, 1, 1>(buf, G.twC, 1, (2 * jn + 2 < nb_last_c) ? jn : -1);
-            STAMP(5);
             const double sc = red[24];
             double* __restrict__ ud = HMG_PRUNED_ULDS ? uls : u;
             for (int j = 1 + (int)threadIdx.x; j <= jn; j += NT) {
@@ -260,9 +230,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
             }
         }
     }
-#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 32)     // timing experiment: no group loop at all
-    chirped = true;
-#endif
     for (int g = 0; g <= R / 2 && !chirped; ++g) {
         if (!pruned_group_needed(R, M, g, jn)) break;          // (groups are needed in ascending order of g)
         const int s1 = pruned_group_partner(R, g), nbuf = s1 < 0 ? 1 : 2;
@@ -286,21 +253,11 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
             }
         }
         __syncthreads();                                       // (also publishes red[24] before the first unpack)
-        STAMP(8 + 3 * g);
-#if !(defined(HMG_LG_ABL) && (HMG_LG_ABL & 4))   // timing experiment: without the passes in LDS
         pruned_passes<NT, LP, 1>(buf, twl, nbuf, keep);
-#endif
-        STAMP(9 + 3 * g);
         const double sc = red[24];
-#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 8)      // timing experiment: without the unpack step
-        if (g == 0 && threadIdx.x < 64) u[threadIdx.x] = buf[threadIdx.x].x * sc;
-        __syncthreads();
-        continue;
-#endif
         pruned_unpack(buf, LP, R, M, g, 0, nbuf == 2 ? 1 : 0, jn, G.twNr, sc, u, (int)threadIdx.x, NT);
         if (nbuf == 2) pruned_unpack(buf, LP, R, M, s1, 1, 0, jn, G.twNr, sc, u, (int)threadIdx.x, NT);
         __syncthreads();                                       // the next group overwrites the buffers
-        STAMP(10 + 3 * g);
     }
     // A chirp row's modes sit by mode number - u_j at [j-1] - in LDS (or, without HMG_PRUNED_ULDS, in the scratch line);
     // the decomposition's in the scratch line by residue.  Mode M (Nyquist, Im F_M == 0) has no slot there: the
@@ -308,7 +265,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
     if (HMG_PRUNED_ULDS && chirped) u = uls;                   // (jn <= Jw < M - 4: mode M is never read)
     else __threadfence_block();
     __syncthreads();                                           // u is read by other threads below
-    STAMP(6);
     // ---- phase D: as profile_fused_row, the modes read from the scratch line
     const double k_lo = red[20], k_hi = red[21], inv_dk = red[22];
     const double pf = A.post ? A.post[row] : 1.0;
@@ -331,9 +287,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         int j = (int)(k * inv_dk);
         j = j < 1 ? 1 : (j > M - 1 ? M - 1 : j);
         const double fr = fma(k, inv_dk, -(double)j);
-#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 16)     // timing experiment: interpolation without the mode loads
-        return fr + (double)j;
-#else
         double y0, y1;
         if (chirped) {
             y0 = u[j - 1]; y1 = u[j];
@@ -345,7 +298,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
             y1 = j + 1 < M ? u[i1] : 0.0;
         }
         return fma(y1 - y0, fr, y0);
-#endif
     };
     if (A.nconst) {
         for (int i = (nleft & ~63) + threadIdx.x; i < A.nk; i += NT) {
@@ -365,10 +317,6 @@ __device__ __forceinline__ void profile_pruned_row(const PrunedArgs& G, int row,
         A.nconst[row] = nleft;
         A.cconst[row] = u1 * pf;
     }
-    STAMP(7);
-#ifdef HMG_LG_STAMP
-    if (stamp_slot >= 0 && threadIdx.x == 0) g_stamps[stamp_slot * 64 + 61] = (long long)wall_clock64();
-#endif
 }
 #ifndef HMG_PRUNED_OCC
 #define HMG_PRUNED_OCC 0
@@ -416,11 +364,7 @@ __global__ void band_tables_kernel(int nxs, int D, int LB, const double* __restr
 }
 
 constexpr bool defined_abl8() {
-#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 8)      // timing experiment: without the accumulation of the band's modes
-    return true;
-#else
     return false;
-#endif
 }
 template <int NT, int LB, int MAXA>
 __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, double* smem) {
@@ -527,10 +471,6 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
                             const int q = (p1 + h) * LB + jb + t * nb0;             // pair p = p1 + h + D p2, p2 = jb + t nb0
                             const double2 xv = xT[q], lv = lT[q], wv = wT[q];
                             double r0 = 0.0, r1 = 0.0;
-#if defined(HMG_LG_ABL) && (HMG_LG_ABL & 64)     // timing experiment: no transcendentals in the integrand
-                            if (!(fabs(xv.x) > cm)) r0 = Aamp * lv.x + AL;
-                            if (!(fabs(xv.y) > cm)) r1 = Aamp * lv.y + EX;
-#else
                             if (alpha1) {
                                 if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_alpha1(lv.x - ln_xc, xv.x * inv_xc, Aamp, EX, A.gamma);
                                 if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_alpha1(lv.y - ln_xc, xv.y * inv_xc, Aamp, EX, A.gamma);
@@ -538,7 +478,6 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
                                 if (!(fabs(xv.x) > cm)) r0 = gnfw_rho_fast(lv.x - ln_xc, Aamp, AL, EX, A.gamma);
                                 if (!(fabs(xv.y) > cm)) r1 = gnfw_rho_fast(lv.y - ln_xc, Aamp, AL, EX, A.gamma);
                             }
-#endif
                             v[t] = cplx{xv.x * r0, xv.y * r1};
                             if (A.do_norm && (r0 != 0.0 || r1 != 0.0))
                                 nrm += wv.x * (r0 * (xv.x * xv.x)) + wv.y * (r1 * (xv.y * xv.y));
@@ -551,9 +490,7 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
             }
         }
         __syncthreads();
-#if !(defined(HMG_LG_ABL) && (HMG_LG_ABL & 4))   // timing experiment: without the passes in LDS
         pruned_passes<NT, LB, 1, HMG_BAND_NBUF>(buf, G.twL, nbuf, keep);
-#endif
         const cplx* __restrict__ twm = G.twR + (size_t)p1 * LB;
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
@@ -746,8 +683,3 @@ int launch_band(hipStream_t stream, int LB, PrunedArgs G, int rows, int jnmax) {
 
 }  // namespace hmg
 
-#ifdef HMG_LG_STAMP
-extern "C" int hmg_debug_stamps(long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hmg::g_stamps), (size_t)n * sizeof(long long));
-}
-#endif

@@ -212,3 +212,47 @@ def test_queue_built_for_one_mass_grid_is_issued_before_the_grid_changes(monkeyp
     ref = state(f)
     ref["P"] = f.get_power("g", "electron")
     assert_same(out[1], ref)
+
+
+@pytest.mark.parametrize("nxs,xmax", [(1000, 20.0), (5000, 20.0), (3000, 7.5)])
+def test_row_scalars_left_by_the_rows_stage_equal_what_a_row_workgroup_works_out(monkeypatch, nxs, xmax):
+    """ABI 8 (hmg_rows_part.d_rowsc): the thread that computes a row's length scale also leaves the output-side scalars
+    of the row's transform - 1/(r(1+z)), k_lo, k_hi, 1/k_lo, 1/kt_1, reachable modes, left-fill count (hmvec/fft.py:96-107) -
+    and the row kernel reads them instead of having one wavefront divide and search.  The record is checked against
+    numpy, and gas and pressure tensors, hints and spectra against the path without it (HMG_NO_ROWSC=1), bit for bit."""
+    import hmvec_amd as hm
+    from hmvec_amd import _native as nat
+    zs = np.linspace(0.05, 2.5, 4)
+    ms = np.geomspace(2e10, 1e17, 90)
+    ks = np.geomspace(1e-4, 100, 300)
+    got = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("HMG_NO_ROWSC", off)
+        h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+        h.add_battaglia_profile("electron", family="AGN", xmax=xmax, nxs=nxs)
+        h.add_battaglia_pres_profile("y", family="pres", xmax=xmax, nxs=nxs)
+        p1, p2 = h.power_device_batch([("electron", "electron"), ("y", "y"), ("nfw", "y")])
+        hint = h.uk_profiles.hint("electron")
+        got[off] = dict(uk=h.uk_profiles["electron"], pk=h.pk_profiles["y"],
+                        n=hint[0].numpy().view(np.int32)[:zs.size * ms.size].copy(), c=hint[1].numpy(),
+                        P=[a.numpy() for a in p1] + [a.numpy() for a in p2])
+        rec = h._pool.get((("uk", "electron"), "rowsc"))
+        assert (rec is None) == (off == "1")
+        if rec is not None:
+            r = rec.numpy().reshape(zs.size * ms.size, nat.ROWSC_STRIDE)
+            rscale = h._pool[(("uk", "electron"), "rowp", 5)].numpy().reshape(-1)
+            z1 = np.repeat(1.0 + zs, ms.size)
+            xs = np.linspace(0.0, xmax, nxs + 1)[1:]
+            kts = np.fft.rfftfreq(xs.size, (xs[-1] - xs[0]) / xs.size) * 2 * np.pi
+            isc = 1.0 / (rscale * z1)
+            assert np.array_equal(r[:, 0], isc) and np.array_equal(r[:, 1], kts[1] * isc)
+            assert np.array_equal(r[:, 2], kts[nxs // 2] * isc) and np.array_equal(r[:, 3], 1.0 / (kts[1] * isc))
+            packed = r[:, 5].copy().view(np.int32).reshape(-1, 2)          # little endian: low word first
+            nleft = np.array([np.searchsorted(ks, klo, side="left") for klo in kts[1] * isc])
+            assert np.array_equal(packed[:, 0], nleft) and np.array_equal(packed[:, 0], got[off]["n"])
+            tmax = ks[-1] * r[:, 3]                                    # the kernel's own product
+            assert np.all(packed[:, 1] == np.where(tmax < nxs // 2 - 4, tmax.astype(int) + 3, nxs // 2))
+    for k in ("uk", "pk", "n", "c"):
+        assert np.array_equal(got["0"][k], got["1"][k]), k
+    for a, b in zip(got["0"]["P"], got["1"]["P"]):
+        assert np.array_equal(a, b)

@@ -51,7 +51,7 @@ for k, v in res["kernels"].items():
 PY
 # SQ issue counters (five more passes), then install both summaries where bench.py reads them, so that the
 # bench line below is derived from the counters of THIS build on THIS box
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r06}
 bash tools/pmc_kernel.sh > $OUT/sq_issue_counters.txt
 cp gpurun_out/pmc_sq/sq_issue_counters.json $OUT/sq_issue_counters.json
 mkdir -p profiles/$ROUND
