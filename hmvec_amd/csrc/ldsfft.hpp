@@ -102,12 +102,10 @@ constexpr bool fft_plan_fill(int M, FftPlanDev& p) {
     // A power-of-two pass right behind a power-of-two first pass stores 16-byte elements at q*(Ns R) + k + t*Ns with
     // Ns R = 8 or 16: the eight lanes of a ds_write_b128 group then fall on two or four 16-byte slots modulo 128 B (a
     // 4-way bank conflict for M = 1000: 2,4,...).  With a radix-5 pass in that place the blocks are 10 or 20 elements
-    // apart and the eight lanes cover all eight slots.  The order of the passes behind the first is free (HMG_PLAN_ORDER=0
-    // in a build keeps the plain ascending order: A/B timing).
-#ifndef HMG_PLAN_ORDER
-#define HMG_PLAN_ORDER 1
-#endif
-    if (HMG_PLAN_ORDER && p.npass >= 3 && (p.radix[0] == 2 || p.radix[0] == 4) && (p.radix[1] == 2 || p.radix[1] == 4)) {
+    // apart and the eight lanes cover all eight slots.  The order of the passes behind the first is free.  (No build
+    // switch here: the host's twiddle tables and the compile-time SubPass plans of BOTH kernel units come from this one
+    // function and must agree.)
+    if (p.npass >= 3 && (p.radix[0] == 2 || p.radix[0] == 4) && (p.radix[1] == 2 || p.radix[1] == 4)) {
         for (int i = 2; i < p.npass; ++i)
             if (p.radix[i] == 5) {
                 for (int j = i; j > 1; --j) p.radix[j] = p.radix[j - 1];

@@ -363,9 +363,6 @@ __global__ void band_tables_kernel(int nxs, int D, int LB, const double* __restr
     wT[q] = make_double2(0.5 * (x1 - xl), 0.5 * (xr - x0));
 }
 
-constexpr bool defined_abl8() {
-    return false;
-}
 template <int NT, int LB, int MAXA>
 __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, double* smem) {
     const FusedArgs& A = G.F;
@@ -495,7 +492,7 @@ __device__ __forceinline__ void profile_band_row(const PrunedArgs& G, int row, d
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
             const int t = threadIdx.x + a * NT;
-            if (t < nslot && !(defined_abl8())) {
+            if (t < nslot) {
                 const int j = band_mode(t, jn), idx = band_index(j, LB), ja = j < 0 ? -j : j;
                 cplx w = twm[ja];                                                  // W_M^(p1 j): residue p1 ...
                 if (j < 0) w.y = -w.y;

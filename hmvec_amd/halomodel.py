@@ -381,10 +381,14 @@ class HaloModel(Cosmology):
                              C.byref(prep) if prep is not None else None)
                 ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), None, None)
                 return prep is not None
+            # the support tag is context state: it is set right around the ONE call it describes and restored whatever
+            # that call does (a call that raises inside a capture must not leave this model's tag behind: ADVICE r05)
             ctx.call_now("hmg_profile_support_epoch", getattr(self, "_epoch", 0))
-            ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), ref("hod") if hod_sums else None,
-                         C.byref(prep) if prep is not None else None)
-            ctx.call_now("hmg_profile_support_epoch", 0)
+            try:
+                ctx.call_now("hmg_group_profile", nz, nm, nk, ref("fft"), ref("hod") if hod_sums else None,
+                             C.byref(prep) if prep is not None else None)
+            finally:
+                ctx.call_now("hmg_profile_support_epoch", 0)
             return prep is not None
         return False
 
@@ -604,9 +608,12 @@ class HaloModel(Cosmology):
             # (the row scalars only travel with the hint arrays: they carry the left-fill count, which needs ks ascending)
             self._queue("fft", nat.ProfileFftPart(*args, nat.ptr(d_rowsc if hint else None)))
         else:
+            ctx.flush()          # deferred stages of ANY model on this context first: their own flush resets the tag
             ctx.call("hmg_profile_support_epoch", getattr(self, "_epoch", 0))
-            ctx.call("hmg_profile_fft", nz, nm, nk, *args)
-            ctx.call("hmg_profile_support_epoch", 0)
+            try:
+                ctx.call("hmg_profile_fft", nz, nm, nk, *args)
+            finally:
+                ctx.call("hmg_profile_support_epoch", 0)
         return out, hint
 
     def _battaglia_rowparams(self, key, kind, fit9, gamma, alpha_const, pref, post_pref, nxs=None, xmax=None):
@@ -851,6 +858,14 @@ class HaloModel(Cosmology):
         """Resolve a tracer name to an hmg_tracer.  `order` is the reference's lookup
         order, which differs between the 1-halo (hods, uk, pk: hmvec.py:516-523) and the
         2-halo (uk, pk, hods: hmvec.py:537-550) code paths."""
+        def tensor(dd, nm_):
+            # (a kernel trusts the pointer it is handed: a hand-assigned entry of another shape must stop here - numpy
+            # would refuse to broadcast it in the reference, hmvec/hmvec.py:516-550)
+            d_ = dd.dev(nm_)
+            if tuple(d_.shape) != (self._nz, self._nm, self._nk):
+                raise ValueError(f"profile {nm_!r} has shape {tuple(d_.shape)}, the model's grid is "
+                                 f"{(self._nz, self._nm, self._nk)}")
+            return d_
         for kind in order:
             if kind == "h" and name in self.hods:
                 hod = self.hods[name]
@@ -859,18 +874,18 @@ class HaloModel(Cosmology):
                 sn = hod["satellite_profile"]
                 hs = self.uk_profiles.hint(sn)
                 hc = self.uk_profiles.hint(cn) if cn is not None else (None, None)
-                t = nat.Tracer(nat.TRACER_HOD, self.uk_profiles.dev(sn).ptr,
-                               None if cn is None else self.uk_profiles.dev(cn).ptr,
+                t = nat.Tracer(nat.TRACER_HOD, tensor(self.uk_profiles, sn).ptr,
+                               None if cn is None else tensor(self.uk_profiles, cn).ptr,
                                d["Nc"].ptr, d["Ns"].ptr, d["NcNs"].ptr, d["NsNsm1"].ptr, d["ngal"].ptr, None,
                                nat.ptr(hs[0]), nat.ptr(hs[1]), nat.ptr(hc[0]), nat.ptr(hc[1]))
                 return t, "h"
             if kind == "m" and name in self.uk_profiles:
                 hp = self.uk_profiles.hint(name)
-                return nat.Tracer(nat.TRACER_MATTER, self.uk_profiles.dev(name).ptr, None, None, None, None, None,
+                return nat.Tracer(nat.TRACER_MATTER, tensor(self.uk_profiles, name).ptr, None, None, None, None, None,
                                   None, None, nat.ptr(hp[0]), nat.ptr(hp[1])), "m"
             if kind == "p" and name in self.pk_profiles:
                 hp = self.pk_profiles.hint(name)
-                return nat.Tracer(nat.TRACER_PRESSURE, self.pk_profiles.dev(name).ptr, None, None, None, None, None,
+                return nat.Tracer(nat.TRACER_PRESSURE, tensor(self.pk_profiles, name).ptr, None, None, None, None, None,
                                   None, None, nat.ptr(hp[0]), nat.ptr(hp[1])), "p"
         raise ValueError
 
@@ -1017,6 +1032,14 @@ class HaloModel(Cosmology):
 
     _SMALL_GRID_BYTES = 32 << 20       # tensors up to this size: every registered tracer rides in the first batch
 
+    def _tensors_valid(self, tn):
+        shape = (self._nz, self._nm, self._nk)
+        for kind, nm_ in tn:
+            d = (self.uk_profiles if kind == "uk" else self.pk_profiles)._dev.get(nm_)
+            if d is None or tuple(d.shape) != shape:
+                return False
+        return True
+
     def _free_riders(self, name, name2):
         """Other registered tracers whose tensors are a subset of what (name, name2) streams
         anyway: their spectra with each other and with the requested pair cost no extra HBM
@@ -1036,7 +1059,9 @@ class HaloModel(Cosmology):
             if cand in names or len(names) >= 4:
                 continue
             tn = self._tensor_names(cand)
-            if tn is not None and (tn <= need or small):
+            # a rider must not be able to break the request it rides with: only tracers whose tensors are on the
+            # device in this model's (nz, nm, nk) shape (a hand-assigned uk_profiles entry can be anything)
+            if tn is not None and (tn <= need or small) and self._tensors_valid(tn):
                 names.append(cand)
         for n_ in names:
             kinds[n_] = self._tracer(n_, "hmp")[1]
@@ -1069,7 +1094,17 @@ class HaloModel(Cosmology):
             per = self._nz * self._nk
             o1 = [blk.view(i * per, (self._nz, self._nk)) for i in range(n)]
             o2 = [blk.view((n + i) * per, (self._nz, self._nk)) for i in range(n)]
-            self.power_device_batch(pairs, outs1=o1, outs2=o2)
+            try:
+                self.power_device_batch(pairs, outs1=o1, outs2=o2)
+            except Exception:
+                # a rider turned out bad after all: the request itself must not fail for it - the minimal batch
+                minimal = [(a, b) for a, b in pairs if {a, b} <= {name, name2}]
+                if len(minimal) == len(pairs):
+                    raise
+                pairs, n = minimal, len(minimal)
+                o1 = [blk.view(i * per, (self._nz, self._nk)) for i in range(n)]
+                o2 = [blk.view((n + i) * per, (self._nz, self._nk)) for i in range(n)]
+                self.power_device_batch(pairs, outs1=o1, outs2=o2)
             hb = _HostBlock(blk)
             for i, ((a, b), d1, d2) in enumerate(zip(pairs, o1, o2)):
                 self._pcache[(a, b)] = (self._version, d1, d2, hb, i, n + i)

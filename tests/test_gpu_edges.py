@@ -550,3 +550,24 @@ def test_structure_compiled_mass_integrals_equal_the_generic_forms(monkeypatch):
             b.compute()
             for p, (x, y) in b.fetch().items():
                 assert np.array_equal(got[p][0], x) and np.array_equal(got[p][1], y), (thin, pairs, p)
+
+
+def test_a_bad_registered_tracer_cannot_break_an_unrelated_request():
+    """on small grids every registered tracer rides in the first batch of mass integrals.  A tracer whose
+    tensor is not in this model's (nz, nm, nk) shape - a hand-assigned uk_profiles entry - must neither ride nor make the
+    request it would have ridden with fail; the requested spectrum equals the one of a model without that entry."""
+    import hmvec_amd as hm
+    zs = np.array([0.2, 1.0])
+    ms = np.geomspace(1e11, 1e16, 40)
+    ks = np.geomspace(1e-3, 30, 64)
+    ref = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    want = ref.get_power("nfw")
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.uk_profiles["broken"] = np.ones((zs.size, ms.size, ks.size // 2))        # wrong k length
+    h.uk_profiles["good"] = np.ones((zs.size, ms.size, ks.size)) * 0.5
+    got = h.get_power("nfw")
+    assert np.array_equal(got, want)
+    assert ("good", "nfw") in h._pcache or ("nfw", "good") in h._pcache          # the valid rider did ride ...
+    assert not any("broken" in k for k in h._pcache)                              # ... the bad one did not
+    with pytest.raises(ValueError):
+        h.get_power("broken")                                                     # asked for by name: refused BEFORE any launch
