@@ -98,6 +98,34 @@ __device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
     c = ((q + 1) & 2) ? -ca : ca;
 }
 
+// +-(sin x - y cos x) for 0 <= x < 2^30 with the SIGN LEFT OPEN: the numerator of the top-hat window (y = x), which
+// the sigma^2 contraction squares.  The same reduction and kernel polynomials as sincos_fast; the quadrant then only
+// decides WHICH of the two kernel values plays the sine - q even: sr - y cr, q odd: cr + y sr - and the two sign flips
+// of sincos_fast drop out (exact negations: the magnitude has the bits of sn - y cs formed from sincos_fast's results).
+__device__ __forceinline__ double sin_minus_ycos_nosign(double x, double y) {
+    const double kd = rint(x * 0.63661977236758134308);
+    double r = fma(-kd, 1.5707963267948966, x);
+    r = fma(-kd, 6.123233995736766e-17, r);
+    r = fma(-kd, -1.4973849048591698e-33, r);
+    const int q = (int)kd;
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double sr = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const double sa = (q & 1) ? cr : sr;          // |sin x|-side value
+    const double cb = (q & 1) ? -sr : cr;         // cos x up to the common sign
+    return sa - y * cb;
+}
+
 // Si(x) and Ci(x) for x > 0 given sx = sin x, cx = cos x and z = 1/x^2 (read for x > 4 only).
 // For x <= 4 the returned "ci" is only the rational part c(x) of
 //     Ci(x) = gamma + ln x + c(x),
