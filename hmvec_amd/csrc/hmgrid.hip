@@ -664,7 +664,9 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             const bool spec2500 = FUSED_NT == 512 && pl.M == 2500 && pl.npass == 5 && pl.radix[0] == 4 && pl.radix[1] == 5 &&
                                   pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
                                   !c->fused_generic;      // (testing: force the run-time plan)
-            const bool grouped = C && nchain > 0 && FUSED_NT == 512;
+            // the group kernels read the rows' output-side scalars from the record of the rows stage; a caller without
+            // one (no hint arrays: ks not ascending) gets the stand-alone row kernel and its chain as a launch of its own
+            const bool grouped = C && nchain > 0 && FUSED_NT == 512 && A.rowsc != nullptr;
             // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 3000, 4000, 6000 (the last one only
             // when its rows' support does not let the long-grid route take it)
             const int ctM = (FUSED_NT == 512 && !c->fused_generic &&

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512, (fused_occ<MAXB, SPECM>())) void profile_group
         chain_row<512>(C, b, smem);
         return;
     }
-    profile_fused_row<512, MAXB, MAXP, SPECM>(A, row_order(b - nchain, A.nm), smem);
+    profile_fused_row<512, MAXB, MAXP, SPECM, false, true>(A, row_order(b - nchain, A.nm), smem);     // (A.rowsc is required)
 }
 
 }  // namespace hmg

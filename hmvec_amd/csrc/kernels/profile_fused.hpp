@@ -82,7 +82,9 @@ template <int MAXB, int SPECM> constexpr int fused_occ() { return MAXB > 2 ? 4 :
 // the pass loop with its dispatch chain unrolls.
 // TAB: the profile is read from a table (a user's callable evaluated on the x grid: hmvec/fft.py:56-94) instead of
 // evaluated from the family; everything behind the integrand is the same code.
-template <int NT, int MAXB, int MAXP, int SPECM, bool TAB = false>
+// RSC: the output-side scalars of the row come from the record the rows stage left (A.rowsc, hmg_rows_part ABI 8) - the
+// grouped launch of the facade; without it one wavefront of the workgroup works them out (stand-alone launches).
+template <int NT, int MAXB, int MAXP, int SPECM, bool TAB = false, bool RSC = false>
 __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, double* smem) {
     // dynamic LDS only (base stays 16 B aligned for the 128-bit complex accesses):
     // [0, 2M) doubles = packed row as cplx, later u[0..M-1]; then 16 doubles of reduction
@@ -119,8 +121,8 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // without loading or testing a wavenumber.
     // (with A.rowsc - the grouped passes of the facade - the launch that computed the rows' length scales left these
     // numbers per row: they arrive by scalar loads and no wavefront of this workgroup divides or searches)
-    const double* __restrict__ rsc = A.rowsc ? A.rowsc + (size_t)row * HMG_ROWSC_STRIDE : nullptr;
-    if (!rsc && threadIdx.x >= NT - 64) {
+    const double* __restrict__ rsc = RSC ? A.rowsc + (size_t)row * HMG_ROWSC_STRIDE : nullptr;
+    if (!RSC && threadIdx.x >= NT - 64) {
         const int lane = threadIdx.x & 63;
         const double isc0 = 1.0 / (A.rss[row] * (1.0 + A.zs[z]));      // kout_j = kts[j] * isc
         const double klo0 = A.kts[1] * isc0;
@@ -208,9 +210,9 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) tot += red[w];
         const double mnorm = A.do_norm ? tot : 1.0;
-        if (threadIdx.x == 0) red[24] = -A.step / mnorm * (rsc ? rsc[4] : red[23]);
+        if (threadIdx.x == 0) red[24] = -A.step / mnorm * (RSC ? rsc[4] : red[23]);
     }
-    const int jn = rsc ? __double2hiint(rsc[5]) : __builtin_amdgcn_readfirstlane(*s_jn);
+    const int jn = RSC ? __double2hiint(rsc[5]) : __builtin_amdgcn_readfirstlane(*s_jn);
     // ---- phase B: in-place Stockham FFT of length M
     // (Tried and dropped, MI355X: fetching all R operands before the twiddle products and requesting the
     // next pass's twiddle between the two halves of a pass.  Both lengthen live ranges under the 64-VGPR
@@ -280,14 +282,14 @@ __device__ __forceinline__ void profile_fused_row(const FusedArgs& A, int row, d
     // ---- phase D: np.interp(ks, kout, u, left=u_1, right=0) on the uniform source grid:
     // bracket j = floor(k/k_lo), weight k/k_lo - j (one FMA), two LDS reads.  The left fill is a
     // plain splat (63 % of the Battaglia tensor at Config 3).
-    const double k_lo = rsc ? rsc[1] : red[20], k_hi = rsc ? rsc[2] : red[21], inv_dk = rsc ? rsc[3] : red[22];
+    const double k_lo = RSC ? rsc[1] : red[20], k_hi = RSC ? rsc[2] : red[21], inv_dk = RSC ? rsc[3] : red[22];
     const double pf = A.post ? A.post[row] : 1.0;
     const double u1 = u[0];
     double* __restrict__ dst = A.out + (size_t)row * A.nk;
     // with the hint arrays the left fill [0, nleft) is a plain fill in 16-byte stores (no wavenumber is loaded or
     // tested) and the interpolation starts at the 64-aligned index below nleft, so that its stores stay on whole
     // 512-byte wavefront segments; without them (ks in any order) every target is tested
-    const int nleft = rsc ? __double2loint(rsc[5]) : (A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0);
+    const int nleft = RSC ? __double2loint(rsc[5]) : (A.nconst ? __builtin_amdgcn_readfirstlane(*s_cnt) : 0);
     if (nleft > 0) {
         typedef double v2d __attribute__((ext_vector_type(2)));
         const double c = u1 * pf;
