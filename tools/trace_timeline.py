@@ -46,10 +46,12 @@ for a, b in run:
         dur[(i - a, K[i][2])].append((K[i][1] - K[i][0]) / 1e3)
         gaps[(i - a, K[i][2])].append((K[i][0] - K[i - 1][1]) / 1e3)
 period = [(K[b][0] - K[a][0]) / 1e3 for a, b in run if b < len(K)]
-print("# averages over the run:                                      duration   gap before")
+import statistics as st
+print("# medians over the run (under the profiler the host can fall behind a 0.1 ms step: the gap in front of a step's first")
+print("# launch is then the host's, which is why means are not quoted):  duration   gap before")
 tot_d = tot_g = 0.0
 for key in sorted(dur):
-    d, g = sum(dur[key]) / len(dur[key]), sum(gaps[key]) / len(gaps[key])
+    d, g = st.median(dur[key]), st.median(gaps[key])
     tot_d += d; tot_g += g
     print(f"  {key[1]:46s}           {d:8.1f}   {g:8.1f}")
-print(f"  {'sum':46s}           {tot_d:8.1f}   {tot_g:8.1f}     step period {sum(period)/len(period):.1f} us")
+print(f"  {'sum':46s}           {tot_d:8.1f}   {tot_g:8.1f}     median step period {st.median(period):.1f} us")
