@@ -36,6 +36,20 @@ HMG_FM_HD double fm_rcp(double x) {
 #endif
 }
 
+// One Horner step p*x + c with a compile-time coefficient c.  gfx950's VOP3 cannot encode a 64-bit literal, and left to
+// itself hipcc prefers the two-address v_fmac_f64 with the coefficient copied into the destination first (two v_mov_b32
+// per step: ~10 % of the profile row kernel's VALU instructions were such copies).  The VOP3 form reads the coefficient
+// from an SGPR pair (two s_mov_b32 on the scalar unit, one constant-bus read): the same fused multiply-add, same bits.
+HMG_FM_HD double fm_hstep(double p, double x, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c));
+    return r;
+#else
+    return fma(p, x, c);
+#endif
+}
+
 // ln x for finite x > 0 (normal).  fdlibm e_log.c reduction: x = 2^k m, m in [sqrt(1/2), sqrt 2),
 // f = m - 1, s = f/(2+f), ln m = f - f^2/2 + s (f^2/2 + R(s^2)), R the degree-7 minimax in s^2.
 HMG_FM_HD double log_fast(double x) {
@@ -49,9 +63,9 @@ HMG_FM_HD double log_fast(double x) {
     const double s = f * fm_rcp(2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double t1 = w * fm_hstep(fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), w, 3.999999999940941908e-01);
+    const double t2 = z * fm_hstep(fm_hstep(fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), w,
+                                            2.857142874366239149e-01), w, 6.666666666666735130e-01);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
@@ -68,16 +82,16 @@ HMG_FM_HD double exp_fast(double y) {
     double r = fma(-kd, 6.93147180559945286227e-01, y);
     r = fma(-kd, 2.31904681384629955842e-17, r);
     double p = fma(r, 1.6059043836821613e-10, 2.08767569878681e-09);     // 1/13!, 1/12!
-    p = fma(p, r, 2.505210838544172e-08);                                  // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);                                  // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);                                 // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);                                   // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);                                  // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);                                 // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);                                  // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);                                 // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);                                 // 1/3!
-    p = fma(p, r, 0.5);
+    p = fm_hstep(p, r, 2.505210838544172e-08);                             // 1/11!
+    p = fm_hstep(p, r, 2.755731922398589e-07);                             // 1/10!
+    p = fm_hstep(p, r, 2.7557319223985893e-06);                            // 1/9!
+    p = fm_hstep(p, r, 2.48015873015873e-05);                              // 1/8!
+    p = fm_hstep(p, r, 1.984126984126984e-04);                             // 1/7!
+    p = fm_hstep(p, r, 1.3888888888888889e-03);                            // 1/6!
+    p = fm_hstep(p, r, 8.333333333333333e-03);                             // 1/5!
+    p = fm_hstep(p, r, 4.1666666666666664e-02);                            // 1/4!
+    p = fm_hstep(p, r, 1.6666666666666666e-01);                            // 1/3!
+    p = fma(p, r, 0.5);                                                    // (0.5 and 1.0 are inline constants)
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     if constexpr (CLAMP) return ldexp(p, (int)fmin(fmax(kd, -2000.0), 2000.0));
