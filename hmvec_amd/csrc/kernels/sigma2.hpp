@@ -85,6 +85,7 @@ __device__ __forceinline__ void sigma2_mfma_block(int bx, int seg, int bz, int n
             const double wt = 1.0 - 0.1 * xx + 0.00357142857143 * xx * xx;
             // numerator sin kR - kR cos kR up to its sign, which the square below does not see (sici.hpp)
             double num = sin_minus_ycos_nosign(fmin(kR, 1.0e9), kR);
+#ifndef HMG_SIG_NOSLOW
             if (__builtin_expect(__any(kR >= 1.0e9), 0)) {
                 if (kR >= 1.0e9) {
                     double sn, cs;
@@ -92,6 +93,7 @@ __device__ __forceinline__ void sigma2_mfma_block(int bx, int seg, int bz, int n
                     num = sn - kR * cs;
                 }
             }
+#endif
             const double wtr = 3.0 * num * rcp_fast(fmax(xx * kR, 1.0e-300));
             const double w = (kR < tswitch) ? wt : wtr;
             a[u] = T.wv[u] * (w * w);

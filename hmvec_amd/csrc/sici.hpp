@@ -109,17 +109,19 @@ __device__ __forceinline__ double sin_minus_ycos_nosign(double x, double y) {
     r = fma(-kd, -1.4973849048591698e-33, r);
     const int q = (int)kd;
     const double z = r * r;
+    // (Horner steps with the coefficient in an SGPR pair - fma_vvs: as literals of a plain fma() each costs two v_mov_b32
+    // into the destination of a v_fmac_f64, 20 of the ~75 VALU instructions of a window)
     double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
+    ps = fma_vvs(ps, z, 2.75573137070700676789e-06);
+    ps = fma_vvs(ps, z, -1.98412698298579493134e-04);
+    ps = fma_vvs(ps, z, 8.33333333332248946124e-03);
+    ps = fma_vvs(ps, z, -1.66666666666666324348e-01);
     const double sr = fma(r * z, ps, r);
     double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
+    pc = fma_vvs(pc, z, -2.75573143513906633035e-07);
+    pc = fma_vvs(pc, z, 2.48015872894767294178e-05);
+    pc = fma_vvs(pc, z, -1.38888888888741095749e-03);
+    pc = fma_vvs(pc, z, 4.16666666666666019037e-02);
     const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
     const double sa = (q & 1) ? cr : sr;          // |sin x|-side value
     const double cb = (q & 1) ? -sr : cr;         // cos x up to the common sign
