@@ -227,6 +227,12 @@ struct BatchArgs {
 //                which is what a thin z-slab (one workgroup per CU) needs.
 constexpr int PB_NV = 16;
 
+// the value lane l of the wavefront holds (l uniform): two v_readlane_b32
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 template <int NT, int NTR, int V, bool W16, unsigned CODE = 0>
 __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs A) {
     extern __shared__ double red[];  // [8][NACC*V][64]: parked sums / pair exchange, then the cross-wave reduction
@@ -411,36 +417,68 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) void power_batch_kernel(BatchArgs
     };
 #pragma unroll
     for (int a = 0; a < NACC; ++a) reduce(acc[a]);
-    if (wv == 0 && live) {
-        double bmc[NTR];  // b_t - C_t
-#pragma unroll
-        for (int t = 0; t < NTR; ++t) {
-            double B = 0.0, C = 0.0;
-            for (int blk = 0; blk < A.nblk; ++blk) {
-                const double* sp = A.sidep + ((size_t)(z * A.nblk + blk) * NTR + t) * 2;
-                B += sp[0];
-                C += sp[1];
-            }
-            const double bias = A.ngal[t] ? B / A.ngal[t][z] : A.bias_const[t];
-            bmc[t] = bias - C;
-        }
+    if (wv == 0) {
+        // what the outputs need besides the integrals is requested FIRST, so that it is in flight during the sums below:
+        // the wavenumbers and P_lin of this tile and the 2 NPAIR output pointers (one block of the argument segment
+        // instead of one scalar load, wait and branch per output)
+        double kv[V], pl[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const int k = k0 + v;
-            const size_t o = (size_t)z * A.nk + k;
-            const double q = A.ks[k] / A.kstar;
-            const double damp = 1.0 - exp(-(q * q));
-            const double plin = A.Pzk ? A.Pzk[o] : 0.0;
-            int p = 0;
+            kv[v] = live ? A.ks[k0 + v] : 1.0;
+            pl[v] = (live && A.Pzk) ? A.Pzk[(size_t)z * A.nk + k0 + v] : 0.0;
+        }
+        double* o1[NPAIR];
+        double* o2[NPAIR];
 #pragma unroll
-            for (int a = 0; a < NTR; ++a) {
+        for (int p = 0; p < NPAIR; ++p) { o1[p] = A.P1h[p]; o2[p] = A.P2h[p]; }
+        // Consistency sums B_t, C_t of the batch's tracers over the 64-mass tiles, in tile order.  One coalesced load
+        // brings a group of whole tiles (64 values) into the lanes and the ordered sums read them out with
+        // v_readlane: as a loop of scalar loads this was one dependent scalar-memory round trip per tile and tracer (24
+        // for Config 3, ~2.7 us) at the tail of every workgroup - on a thin z-slab, of the launch.  Same order of
+        // additions, same bits.  (All 64 lanes take part: a lane without a live wavenumber still holds its value.)
+        double bmc[NTR];  // b_t - C_t
+        {
+            double Bs[NTR], Cs[NTR];
 #pragma unroll
-                for (int b = a; b < NTR; ++b) {
-                    if (A.P1h[p]) A.P1h[p][o] = acc[NTR + p][v] * damp;
-                    // (the two brackets are multiplied first: commutative, so the result does not depend on
-                    // which of the two tracers got the lower index in this batch)
-                    if (A.P2h[p]) A.P2h[p][o] = plin * ((acc[a][v] + bmc[a]) * (acc[b][v] + bmc[b]));
-                    ++p;
+            for (int t = 0; t < NTR; ++t) Bs[t] = Cs[t] = 0.0;
+            constexpr int CH = 64 / (2 * NTR);                      // whole tiles per trip
+            const double* __restrict__ spz = A.sidep + (size_t)z * A.nblk * (NTR * 2);
+            for (int blk0 = 0; blk0 < A.nblk; blk0 += CH) {
+                const int nb = min(CH, A.nblk - blk0);
+                const double val = lane < nb * NTR * 2 ? spz[(size_t)blk0 * (NTR * 2) + lane] : 0.0;
+                for (int b = 0; b < nb; ++b) {
+#pragma unroll
+                    for (int t = 0; t < NTR; ++t) {
+                        Bs[t] += lane_value(val, (b * NTR + t) * 2);
+                        Cs[t] += lane_value(val, (b * NTR + t) * 2 + 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTR; ++t) {
+                const double bias = A.ngal[t] ? Bs[t] / A.ngal[t][z] : A.bias_const[t];
+                bmc[t] = bias - Cs[t];
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int k = k0 + v;
+                const size_t o = (size_t)z * A.nk + k;
+                const double q = kv[v] / A.kstar;
+                const double damp = 1.0 - exp(-(q * q));
+                const double plin = pl[v];
+                int p = 0;
+#pragma unroll
+                for (int a = 0; a < NTR; ++a) {
+#pragma unroll
+                    for (int b = a; b < NTR; ++b) {
+                        if (o1[p]) o1[p][o] = acc[NTR + p][v] * damp;
+                        // (the two brackets are multiplied first: commutative, so the result does not depend on
+                        // which of the two tracers got the lower index in this batch)
+                        if (o2[p]) o2[p][o] = plin * ((acc[a][v] + bmc[a]) * (acc[b][v] + bmc[b]));
+                        ++p;
+                    }
                 }
             }
         }
