@@ -232,3 +232,52 @@ def test_no_block_changes_hands_inside_a_capture():
     d, e = ctx.empty((777,)), ctx.empty((777,))
     assert ptr_k in (d.ptr, e.ptr)              # ... and back in circulation once the graph is gone
     ctx.close()
+
+
+def test_a_recorded_call_list_reissues_the_pass():
+    """bench.py's default launch mode (round 6): the native calls of a pass recorded once (Context.trace) and re-issued
+    eagerly without the facade (Context.run_trace).  The list holds raw pointers: re-issued after the CONTENTS of an input
+    changed in place it must give what a fresh eager pass gives on those contents, bit for bit; and it must hold exactly
+    the four launches of a grouped pass."""
+    import hmvec_amd as hm
+    zs = np.linspace(0.1, 2.5, 6)
+    ms = np.geomspace(2e10, 1e17, 96)
+    ks = np.geomspace(1e-4, 100, 384)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000)
+    thr = 10 ** 10.5 + zs * 0.0
+    h.add_hod("g", mthresh=thr)
+    blk = h.spectra_block(PAIRS)
+
+    def step():
+        h.init_mass_function(ms)
+        h.add_nfw_profile("nfw", ignore_existing=True)
+        h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000, ignore_existing=True)
+        h.add_hod("g", mthresh=thr, ignore_existing=True)
+        blk.compute()
+
+    step()
+    eager = {p: (a.copy(), b.copy()) for p, (a, b) in blk.fetch().items()}
+    ctx = h._ctx()
+    calls = ctx.trace(step)
+    launches = [name for name, _ in calls if name in ("hmg_sigma2_halo_front", "hmg_group_rows", "hmg_group_profile",
+                                                       "hmg_power_batch_run")]
+    assert launches == ["hmg_sigma2_halo_front", "hmg_group_rows", "hmg_group_profile", "hmg_power_batch_run"], calls
+    for _ in range(3):
+        ctx.run_trace(calls)
+    got = blk.fetch()
+    for p in PAIRS:
+        assert np.array_equal(got[p][0], eager[p][0]) and np.array_equal(got[p][1], eager[p][1]), p
+    # new contents in the SAME device buffer (the thresholds the occupations read): the list sees them
+    key = [k for k in h._dcache if isinstance(k, tuple) and k[0] == "thr"][0]
+    host_thr, d_thr = h._dcache[key]
+    ctx.write(d_thr, host_thr + 0.25)
+    ctx.run_trace(calls)
+    listed = {p: (a.copy(), b.copy()) for p, (a, b) in blk.fetch().items()}
+    assert not np.array_equal(listed[PAIRS[2]][0], eager[PAIRS[2]][0])
+    h2 = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic")
+    h2.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000)
+    h2.add_hod("g", mthresh=thr * 10 ** 0.25)
+    for p in PAIRS:
+        assert np.allclose(listed[p][0], h2.get_power_1halo(*p), rtol=1e-11, atol=0), p
+        assert np.allclose(listed[p][1], h2.get_power_2halo(*p), rtol=1e-11, atol=0), p
