@@ -234,12 +234,13 @@ def test_no_block_changes_hands_inside_a_capture():
     ctx.close()
 
 
-def test_a_recorded_call_list_reissues_the_pass():
+def test_a_recorded_call_list_reissues_the_pass(monkeypatch):
     """bench.py's default launch mode (round 6): the native calls of a pass recorded once (Context.trace) and re-issued
     eagerly without the facade (Context.run_trace).  The list holds raw pointers: re-issued after the CONTENTS of an input
     changed in place it must give what a fresh eager pass gives on those contents, bit for bit; and it must hold exactly
     the four launches of a grouped pass."""
     import hmvec_amd as hm
+    monkeypatch.setenv("HMG_NO_GROUPS", "0")      # (the launch count below is the grouped pass's)
     zs = np.linspace(0.1, 2.5, 6)
     ms = np.geomspace(2e10, 1e17, 96)
     ks = np.geomspace(1e-4, 100, 384)

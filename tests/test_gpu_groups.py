@@ -215,13 +215,15 @@ def test_queue_built_for_one_mass_grid_is_issued_before_the_grid_changes(monkeyp
 
 
 @pytest.mark.parametrize("nxs,xmax", [(1000, 20.0), (5000, 20.0), (3000, 7.5)])
-def test_row_scalars_left_by_the_rows_stage_equal_what_a_row_workgroup_works_out(monkeypatch, nxs, xmax):
+def test_row_scalars_left_by_the_rows_stage_equal_what_a_row_workgroup_works_out(default_routes, nxs, xmax):
     """ABI 8 (hmg_rows_part.d_rowsc): the thread that computes a row's length scale also leaves the output-side scalars
     of the row's transform - 1/(r(1+z)), k_lo, k_hi, 1/k_lo, 1/kt_1, reachable modes, left-fill count (hmvec/fft.py:96-107) -
     and the row kernel reads them instead of having one wavefront divide and search.  The record is checked against
     numpy, and gas and pressure tensors, hints and spectra against the path without it (HMG_NO_ROWSC=1), bit for bit."""
     import hmvec_amd as hm
     from hmvec_amd import _native as nat
+    monkeypatch = default_routes              # (this test is ABOUT the grouped route with hints: pin it under tools/env_matrix.sh)
+    monkeypatch.setenv("HMG_NO_GROUPS", "0")
     zs = np.linspace(0.05, 2.5, 4)
     ms = np.geomspace(2e10, 1e17, 90)
     ks = np.geomspace(1e-4, 100, 300)
