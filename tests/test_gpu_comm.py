@@ -191,3 +191,34 @@ def test_two_rank_slab_rehearsal_reproduces_the_full_grid(tmp_path, nz):
         for key in got.files:
             a, b, i = key.split("|")
             assert np.array_equal(got[key], ref[(a, b)][int(i)]), (r, key)
+
+
+@pytest.mark.parametrize("mode", ["call-list", "graph"])
+def test_bench_line_of_a_two_rank_run(tmp_path, mode):
+    """bench.py's N > 1 branch end to end on one device (file transport instead of RCCL, tests/helpers/bench_rank.py): rank 0
+    prints ONE JSON line with the whole-job value, max-over-ranks timing, the strong-scaling label and the collective
+    timed on its own (gather_ms_per_step); the other rank prints nothing."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "helpers", "bench_rank.py")
+    flags = ["--gpus", "2", "--steps", "6", "--warmup", "2", "--nz", "6", "--nm", "96", "--nk", "384", "--nxs", "1000",
+             "--no-cpu-baseline", "--no-readme", "--no-long-grid"] + (["--graph"] if mode == "graph" else [])
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29555",
+                   HMG_LAUNCH_TAG=f"b{os.getpid()}_{mode}", HMG_REHEARSAL_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, worker] + flags, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["gather_ms_per_step"] > 0 and d["gather"]["max_over_ranks_ms"] >= d["gather"]["min_over_ranks_ms"]
+    assert abs(d["value"] - 6 * 6 * 96 * 384 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["launch_modes"]["timed"]["mode"] != d["launch_modes"]["other"]["mode"]
+    assert d["limber"]["ells"] == 2000
