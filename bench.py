@@ -765,8 +765,11 @@ def main():
     model_source = ("model (stored profile stale: " + stale_pmc[0].split(": ", 1)[1] + ")") if stale_pmc else \
         ("model (DESIGN.md section 4; no stored counter profile applies to this configuration)")
     grouped = h._groups
+    # Tensor group (round 6, hmg_group_tensors): the NFW rows ride in the profile rows' launch - no NFW launch, its bracket
+    # is never recorded, and the "fft" bracket times the one kernel that writes both tensors.
+    tensor = grouped and kms["nfw"] is None and kms["fft"] is not None
     KNAME = {"power": "power_batch_kernel", "nfw": "rows_group_kernel" if grouped else "nfw_kernel",
-             "fft": "profile_group_kernel" if grouped else "profile_fused_kernel"}
+             "fft": ("tensor_group_kernel" if tensor else "profile_group_kernel") if grouped else "profile_fused_kernel"}
 
     def pmc_bytes(sub):
         if not pmc:
@@ -797,6 +800,9 @@ def main():
            "nfw": tens_bytes,
            "fft": 2 * 8.0 * B * nxs + 2 * 16.0 * B * (nxs // 2 + 1) + tens_bytes}     # SURVEY 8d W_fft (unfused chain)
     model = {"power": pw_model, "nfw": tens_bytes + 8.0 * B * 40, "fft": tens_bytes + 8.0 * B * 10}
+    if tensor:
+        model["fft"] += model["nfw"]
+        alg["fft"] += alg["nfw"]
     # The ALGORITHMIC bytes of THIS design: every (z,m,k) tensor crosses HBM exactly twice - written
     # once by its producer, read once by the batched mass integrals - plus the per-(z,m) side arrays.  SURVEY 8d's model
     # (`alg`) prices the reference's unfused pipeline: integrand and spectrum arrays of the FFT chain in HBM (here: LDS) and
@@ -809,6 +815,8 @@ def main():
             "power": 8.0 * B * (8 + 2) + 8.0 * nzl * nk_ * (2 * npair + 1)}                              # coefficient rows + hints in, P_lin in, 12 spectra out
     design = {"front": side["front"], "nfw": tens_bytes + side["nfw"], "fft": tens_bytes + side["fft"],
               "power": 2 * tens_bytes + side["power"]}
+    if tensor:
+        design["fft"] += design.pop("nfw")
     design_step = float(sum(design.values()))
 
     def kernel_entry(key, sub, bound, note):
@@ -836,11 +844,19 @@ def main():
         "profile_fused_kernel": kernel_entry("fft", KNAME["fft"], "fp64-valu + LDS",
                                              "integrand + in-LDS packed-real FFT + k-interpolation per (z,m) row; "
                                              "HBM traffic = the output row"
-                                             + ("; launched as hmg::profile_group_kernel: per-z chain (HOD sums -> "
+                                             + ("; launched as hmg::tensor_group_kernel: per-z chain (sigma^2 -> n, b -> HOD "
+                                                "sums -> coefficient rows) | profile rows | analytic NFW rows in one grid: "
+                                                "ms, bytes and instruction counts are those of BOTH tensors' rows" if tensor else
+                                                "; launched as hmg::profile_group_kernel: per-z chain (HOD sums -> "
                                                 "coefficient rows) | profile rows in one grid" if grouped else "")),
     }
+    if tensor:
+        kernels["nfw_kernel"] = {"bound": "fp64-valu", "ms": None, "launched_as": "hmg::tensor_group_kernel",
+                                 "note": "no launch of its own: the analytic NFW rows ride in hmg::tensor_group_kernel (see "
+                                         "profile_fused_kernel); HMG_NO_TENSOR_GROUP=1 restores the rows group launch"}
     for key, name in (("power_batch_kernel", "power"), ("nfw_kernel", "nfw"), ("profile_fused_kernel", "fft")):
-        kernels[key]["launched_as"] = "hmg::" + KNAME[name]
+        if not (tensor and name == "nfw"):
+            kernels[key]["launched_as"] = "hmg::" + KNAME[name]
     pw = kernels["power_batch_kernel"]
     # the kernel the step spends most of its time in is VALU/LDS-bound, not HBM-bound: its own roofline block
     dom_key = max(kernels, key=lambda k: kernels[k]["ms"] or 0.0)
@@ -1021,6 +1037,7 @@ def main():
                             "mass integrals" if grouped else "one launch per stage (HMG_NO_GROUPS=1)"),
         "kernel_source_sha16": sha, "stale_profiles_ignored": stale or None,
         "brackets_missing": brackets_missing or None,
+        "brackets_missing_note": ("nfw: by design - the NFW rows have no launch of their own (tensor group)" if tensor else None),
         "step_hbm_bytes": step_bytes,
         "step_hbm_bytes_source": (f"pmc (profiles/{PROFILE_ROUND}/pmc_traffic.json, all kernels of a step)" if pmc else model_source),
         "step_hbm_frac": step_bytes / (dt_max / K) / 1e9 / HBM_PEAK_GBS,

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmgrid.so")   # override: tuning experiments only
-ABI_VERSION = 8
+ABI_VERSION = 9
 COMM_ID_BYTES = 128
 
 c_double_p = C.c_void_p  # device or host pointers travel as plain addresses
@@ -173,6 +173,8 @@ SIGNATURES = {
     "hmg_group_rows": [_P, _I, _I, _I, _I, C.POINTER(MassFnPart), C.POINTER(HodPart), C.POINTER(RowsPart),
                        C.POINTER(NfwPart)],
     "hmg_group_profile": [_P, _I, _I, _I, C.POINTER(ProfileFftPart), C.POINTER(HodPart), C.POINTER(PowerBatchDesc)],
+    "hmg_group_tensors": [_P, _I, _I, _I, _I, C.POINTER(MassFnPart), C.POINTER(HodPart), C.POINTER(PowerBatchDesc),
+                          C.POINTER(NfwPart), C.POINTER(ProfileFftPart)],
     "hmg_power_batch_run": [_P, _I, _I, _I, C.POINTER(PowerBatchDesc), _I],
     "hmg_add": [_P, _Z, _P, _P, _P],
     "hmg_limber": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],

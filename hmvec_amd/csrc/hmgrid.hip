@@ -375,11 +375,26 @@ static int launch_table(hmg_ctx* c, const FusedArgs& A, int rows) {
     return 0;
 }
 
-// profile_group_kernel = the fused row kernel with `nchain` per-z chain workgroups in front of the rows
+// profile_group_kernel = the fused row kernel with `nchain` per-z chain workgroups in front of the rows;
+// with N: tensor_group_kernel, the analytic NFW rows behind them in the same grid
 template <int MAXB, int MAXP, int SPECM = 0>
-static int launch_fused_group(hmg_ctx* c, const FusedArgs& A, int rows, const ChainArgs& C, int nchain, size_t chain_lds) {
+static int launch_fused_group(hmg_ctx* c, const FusedArgs& A, int rows, const ChainArgs& C, int nchain, size_t chain_lds,
+                              const NfwArgs* N = nullptr, size_t nfw_blocks = 0) {
     size_t lds = (size_t)A.plan.M * 16 + 32 * sizeof(double);
     if (chain_lds > lds) lds = chain_lds;
+    if (N || C.has_mf) {      // (only the tensor kernel carries the chain's sigma^2 -> n, b link)
+        const NfwArgs none{};
+        if (!N) { N = &none; nfw_blocks = 0; }
+        REQUIRE((size_t)rows + nchain + nfw_blocks <= 2147483647u, "bad grid");
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)tensor_group_kernel<MAXB, MAXP, SPECM>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tensor_group_kernel<MAXB, MAXP, SPECM>), dim3((unsigned)(rows + nchain + nfw_blocks)), dim3(FUSED_NT),
+                           lds, c->stream, C, A, nchain, rows, N->T, N->acoef, N->ktile, N->nm, N->nk, N->cs, N->rss, N->zs,
+                           N->ks, N->uk);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)profile_group_kernel<MAXB, MAXP, SPECM>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -582,9 +597,11 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, bool ca
 // the launch, otherwise *chain_done stays 0 and the caller issues the chain on its own.
 // rho_tab != nullptr: the profile comes from a table (hmg_profile_fft_table); *taken = 0 when no in-LDS route takes the
 // launch (the caller then runs its rocFFT chain); the family parameters of p are not read.
+// N != nullptr: analytic NFW rows that may ride in the same launch when chain and rows share one (*nfw_done = 1 then).
 static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part& p, const ChainArgs* C,
                             int nchain, size_t chain_lds, int* chain_done, const double* rho_tab = nullptr,
-                            int rho_shared = 0, int* taken = nullptr) {
+                            int rho_shared = 0, int* taken = nullptr, const NfwArgs* N = nullptr, size_t nfw_blocks = 0,
+                            int* nfw_done = nullptr) {
     const int nxs = p.nxs;
     const double step = p.fft_step;
     const double *xs = p.d_xs, *kts = p.d_kts, *amp = p.d_amp, *xcs = p.d_xc, *alpha = p.d_alpha, *expo = p.d_expo;
@@ -595,6 +612,7 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
     int* nconst = p.d_nconst;
     double* cconst = p.d_cconst;
     if (chain_done) *chain_done = 0;
+    if (nfw_done) *nfw_done = 0;
     REQUIRE(c && xs && kts && cmax && rss && zs && ks && out, "NULL argument");
     REQUIRE((nconst == nullptr) == (cconst == nullptr), "pass both hint arrays or neither");
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
@@ -672,17 +690,18 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             const int ctM = (FUSED_NT == 512 && !c->fused_generic &&
                              (pl.M == 500 || pl.M == 1000 || pl.M == 1500 || pl.M == 2000 || pl.M == 3000)) ? pl.M : 0;
             if (grouped) {
-                if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds);
-                else if (ctM == 500) rc = launch_fused_group<1, 1, 500>(c, A, rows, *C, nchain, chain_lds);
-                else if (ctM == 1000) rc = launch_fused_group<1, 1, 1000>(c, A, rows, *C, nchain, chain_lds);
-                else if (ctM == 1500) rc = launch_fused_group<1, 2, 1500>(c, A, rows, *C, nchain, chain_lds);
-                else if (ctM == 2000) rc = launch_fused_group<2, 2, 2000>(c, A, rows, *C, nchain, chain_lds);
-                else if (ctM == 3000) rc = launch_fused_group<3, 3, 3000>(c, A, rows, *C, nchain, chain_lds);
-                else if (mb <= 1 && mp <= 2) rc = launch_fused_group<1, 2>(c, A, rows, *C, nchain, chain_lds);
-                else if (mb <= 2 && mp <= 3) rc = launch_fused_group<2, 3>(c, A, rows, *C, nchain, chain_lds);
-                else if (mb <= 2 && mp <= 4) rc = launch_fused_group<2, 4>(c, A, rows, *C, nchain, chain_lds);
-                else rc = launch_fused_group<4, 8>(c, A, rows, *C, nchain, chain_lds);
+                if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (ctM == 500) rc = launch_fused_group<1, 1, 500>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (ctM == 1000) rc = launch_fused_group<1, 1, 1000>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (ctM == 1500) rc = launch_fused_group<1, 2, 1500>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (ctM == 2000) rc = launch_fused_group<2, 2, 2000>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (ctM == 3000) rc = launch_fused_group<3, 3, 3000>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (mb <= 1 && mp <= 2) rc = launch_fused_group<1, 2>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (mb <= 2 && mp <= 3) rc = launch_fused_group<2, 3>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else if (mb <= 2 && mp <= 4) rc = launch_fused_group<2, 4>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
+                else rc = launch_fused_group<4, 8>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
                 if (!rc && chain_done) *chain_done = 1;
+                if (!rc && N && nfw_done) *nfw_done = 1;
             }
             else if (spec2500) rc = launch_fused<2, 3, 2500>(c, A, rows);                 // nxs = 5000, compile-time plan
             else if (ctM == 500) rc = launch_fused<1, 1, 500>(c, A, rows);
@@ -1157,7 +1176,7 @@ int hmg_sigma2_halo_front(hmg_ctx* c, int nz, int nm, int nq, const double* PT, 
 
 // the optional links of a per-z chain from their parts; *n = 1 if there is any
 static int chain_setup(int nm, const hmg_hod_part* hod, const PbPlan* prep, ChainArgs* C, int* n) {
-    C->has_hod = C->has_prep = 0;
+    C->has_hod = C->has_prep = C->has_mf = C->mf_pad = 0;
     if (hod) {
         REQUIRE(hod->stage == HMG_HOD_SUMS, "a chain takes the n_gal, b_g sums of an HOD (its occupations ride with the front)");
         if (hod_args(nm, hod, &C->H)) return 1;
@@ -1249,6 +1268,56 @@ int hmg_group_profile(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_
         const RowsArgs none{};
         if (launch_rows_group(c, nz, nm, C, nz, nullptr, none, nullptr, 0)) return 1;
     }
+    if (prep && !P.code) {         // generic coefficient rows (register-hungry): a launch of their own
+        hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, P.PA.nblk), dim3(64), 0, c->stream, P.PA);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int hmg_group_tensors(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_massfn_part* mf, const hmg_hod_part* hod,
+                      const hmg_power_batch_desc* prep, const hmg_nfw_part* nfw, const hmg_profile_fft_part* fft) {
+    REQUIRE(c, "NULL ctx");
+    REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
+    REQUIRE(fft, "the tensor group is built around the rows of a profile transform: use hmg_group_rows without one");
+    REQUIRE((nm + 63) / 64 <= HOD_MAX_TILES, "nm too large");
+    // Will the transform share its launch?  (one row in LDS with the row scalars of the rows stage: the decision of
+    // profile_fft_impl for such a length.)  If not - long grids, the rocFFT route, no hint arrays - the two groups run
+    // one after the other, as the two calls would.
+    bool merge = c->use_fused_fft && fft->d_xs && ((uintptr_t)fft->d_xs % 16) == 0 && fft->d_rowsc && fft->d_nconst &&
+                 FUSED_NT == 512 && (hod || prep || mf) && !getenv("HMG_NO_TENSOR_GROUP");
+    if (merge) {
+        FusedPlan* FP = nullptr;
+        if (get_fused_plan(c, fft->nxs, &FP)) return 1;
+        merge = FP && !(FP->plan.M > c->fused_prefer_m && c->use_pruned_fft);
+    }
+    if (!merge) {
+        if ((mf || nfw) && hmg_group_rows(c, nz, nm, nk, nq, mf, nullptr, nullptr, nfw)) return 1;
+        return hmg_group_profile(c, nz, nm, nk, fft, hod, prep);
+    }
+    PbPlan P;
+    if (prep && pb_plan(c, nz, nm, nk, prep, &P)) return 1;
+    ChainArgs C;
+    int one = 0;
+    if (chain_setup(nm, hod, prep ? &P : nullptr, &C, &one)) return 1;
+    if (mf) {           // sigma^2 -> n, b as the first link of the chain: every later link reads what its own workgroup wrote
+        if (massfn_setup(c, nz, nm, nq, mf, &C.S)) return 1;
+        C.has_mf = 1;
+        one = 1;
+    }
+    NfwArgs N{};
+    size_t nfw_blocks = 0;
+    if (nfw) {
+        REQUIRE(nfw->d_cs && nfw->d_rs && nfw->d_zs && nfw->d_ks && nfw->d_nfw_series && nfw->d_uk, "NULL argument in the NFW part");
+        const int ktile = 4096;
+        nfw_blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
+        N = NfwArgs{c->d_sici, nfw->d_nfw_series, ktile, nm, nk, nfw->d_cs, nfw->d_rs, nfw->d_zs, nfw->d_ks, nfw->d_uk};
+    }
+    int chain_done = 0, nfw_done = 0;
+    if (profile_fft_impl(c, nz, nm, nk, *fft, &C, one ? nz : 0, chain_lds_doubles(nm, C.has_mf != 0, 512) * 8, &chain_done,
+                         nullptr, 0, nullptr, nfw ? &N : nullptr, nfw_blocks, &nfw_done))
+        return 1;
+    REQUIRE((!one || chain_done) && (!nfw || nfw_done), "internal: the transform did not take the route the tensor group was set up for");
     if (prep && !P.code) {         // generic coefficient rows (register-hungry): a launch of their own
         hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, P.PA.nblk), dim3(64), 0, c->stream, P.PA);
         HIP_TRY(hipGetLastError());

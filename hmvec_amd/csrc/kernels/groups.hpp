@@ -67,9 +67,14 @@ struct ChainArgs {
     int has_hod, has_prep;
     HodRowArgs H;
     PrepArgs PA;
+    int has_mf, mf_pad;        // first link sigma^2 -> n, b (all masses of the redshift, massfn_row)
+    SigmaMassFnArgs S;
 };
-// doubles of LDS a chain workgroup needs
-static inline size_t chain_lds_doubles(int nm) { return 2 * (size_t)((nm + 63) / 64); }
+// doubles of LDS a chain workgroup of nt threads needs (the links use it one after the other)
+static inline size_t chain_lds_doubles(int nm, bool has_mf = false, int nt = 512) {
+    const size_t hod = 2 * (size_t)((nm + 63) / 64), mf = has_mf ? (size_t)nt : 0;
+    return hod > mf ? hod : mf;
+}
 // The chain is kept LIGHT on purpose - the n_gal, b_g sums of an HOD and the compact coefficient rows: loads, a
 // few divisions, wavefront sums - so that it fits the register budget of the launch it rides in without a
 // spill.  Everything heavy of the HOD (its occupation numbers: SHMR inversion, erf, powers) is in the front
@@ -96,8 +101,15 @@ __device__ __forceinline__ T kernarg_load(const T HMG_KERNARG* p) {      // a by
 // of a workgroup skipped a barrier (a launch that never finished); read through __builtin_amdgcn_kernarg_segment_ptr()
 // INSIDE a called function the argument block sits at address 0 (a memory fault).  DESIGN.md section 3, "What stalled
 // and what aborted in round 3".
-template <int NT>
+// MF: the launch is compiled with the sigma^2 -> n, b link (its erfc / exp / pow need ~30 registers more than the
+// other links: only the tensor group carries it)
+template <int NT, bool MF = false>
 __device__ __forceinline__ void chain_row(const ChainArgs& C, int z, double* lds) {
+    if (MF && C.has_mf) {
+        massfn_row<NT>(C.S, z, lds);
+        __threadfence_block();                 // n, b of this redshift are read back below by other threads of the workgroup
+        __syncthreads();
+    }
     if (C.has_hod) {
         hod_sums_row(C.H, z, NT, lds);
         __syncthreads();
@@ -165,6 +177,27 @@ __global__ __launch_bounds__(512, (fused_occ<MAXB, SPECM>())) void profile_group
         return;
     }
     profile_fused_row<512, MAXB, MAXP, SPECM, false, true>(A, row_order(b - nchain, A.nm), smem);     // (A.rowsc is required)
+}
+
+// tensor group (512 threads): per-z chain INCLUDING sigma^2 -> n, b | fused radial-profile rows | analytic NFW rows -
+// everything between the front and the mass integrals as one launch (the chain's first link used to be mass tiles of the
+// rows group, a launch of its own in front of this one: ~11 us of a 0.1 ms thin-slab step).  The two kinds of rows are
+// both bound by fp64 issue and take the sum of their times, one kernel boundary less.  Profile rows first: measured
+// against alternating rows and NFW rows first on MI355X (0.308 / 0.324 / 0.321 ms at nz = 32).
+template <int MAXB, int MAXP, int SPECM>
+__global__ __launch_bounds__(512, (fused_occ<MAXB, SPECM>())) void tensor_group_kernel(
+    ChainArgs C, FusedArgs A, int nchain, int nprof, const SiciTable* __restrict__ T, const double* __restrict__ acoef,
+    int ktile, int nm, int nk, const double* __restrict__ cs, const double* __restrict__ rss,
+    const double* __restrict__ zs, const double* __restrict__ ks, double* __restrict__ uk) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int b = blockIdx.x;
+    if (b < nchain) {
+        chain_row<512, true>(C, b, smem);
+        return;
+    }
+    b -= nchain;
+    if (b < nprof) profile_fused_row<512, MAXB, MAXP, SPECM, false, true>(A, row_order(b, A.nm), smem);
+    else nfw_rows(T, acoef, ktile, nm, nk, cs, rss, zs, ks, uk, b - nprof, 512, threadIdx.x);
 }
 
 }  // namespace hmg

@@ -156,4 +156,36 @@ __device__ __forceinline__ void sigma2_massfn_tile(const SigmaMassFnArgs& A, int
     }
 }
 
+// The same stage for ALL masses of one redshift by ONE workgroup of NT threads: the form the per-z chain uses when
+// sigma^2 -> n, b is its first link (tensor group: the chain then needs nothing from another workgroup of its launch, and
+// a serial walk over the 62-mass tiles above would be the longest thing in it).  One mass per thread: the thread sums
+// the four interleaved part groups of its mass itself (same groups, same order, ((g0 + g1) + g2) + g3: the bits of
+// sigma2_combine_kernel), the values go to LDS, every thread evaluates n, b of its mass from there.  Mass grids longer
+// than NT in chunks of NT - 2 masses with their two stencil neighbours.  sig: NT doubles of LDS.
+template <int NT>
+__device__ __forceinline__ void massfn_row(const SigmaMassFnArgs& A, int z, double* sig) {
+    const int nm = A.nm, n = A.nz * nm, t = (int)threadIdx.x;
+    const bool one = nm <= NT;
+    const int stride = one ? NT : NT - 2;
+    for (int first = 0; first < nm; first += stride) {
+        const int base = one ? 0 : first - 1;                 // mass of slot 0
+        const int m = base + t;                               // this thread's slot (clamped to the row for the sum)
+        const size_t i = (size_t)z * nm + min(max(m, 0), nm - 1);
+        const double g0 = sigma2_segment_sum(n, A.parts, A.partial, i, 0), g1 = sigma2_segment_sum(n, A.parts, A.partial, i, 1);
+        const double g2 = sigma2_segment_sum(n, A.parts, A.partial, i, 2), g3 = sigma2_segment_sum(n, A.parts, A.partial, i, 3);
+        const double v = ((g0 + g1) + g2) + g3;
+        sig[t] = v;
+        const bool mine = m < nm && (one || (t >= 1 && t <= NT - 2));
+        if (mine) A.s2[i] = v;
+        __syncthreads();
+        if (mine) {
+            double nn, bb;
+            massfn_point(A.P, z, m, nm, [&](int k) { return sig[k - base]; }, A.ms, A.lnm, A.tz, nn, bb);
+            A.nzm[i] = nn;
+            A.bh[i] = bb;
+        }
+        __syncthreads();                                      // the next chunk overwrites sig
+    }
+}
+
 }  // namespace hmg

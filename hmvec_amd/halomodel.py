@@ -367,6 +367,15 @@ class HaloModel(Cosmology):
             h = st.pop("hod")
             ctx.call_now("hmg_hod", nz, nm, h.h_par, h.d_zs, h.d_ms, h.d_log10mstar_thresh, h.d_nzm, h.d_bh, h.d_wm,
                          h.d_Nc, h.d_Ns, h.d_NsNsm1, h.d_NcNs, h.d_ngal, h.d_bg)
+        if "fft" in st and ("massfn" in st or "nfw" in st) and "rows" not in st and not x:
+            # tensor group: chain (sigma^2 -> n, b -> HOD sums -> coefficient rows) | profile rows | NFW rows, one launch
+            ctx.call_now("hmg_profile_support_epoch", getattr(self, "_epoch", 0))
+            try:
+                ctx.call_now("hmg_group_tensors", nz, nm, nk, nq, ref("massfn"), ref("hod") if hod_sums else None,
+                             C.byref(prep) if prep is not None else None, ref("nfw"), ref("fft"))
+            finally:
+                ctx.call_now("hmg_profile_support_epoch", 0)
+            return prep is not None
         nfw_alone = st.pop("nfw") if "nfw_alone" in x and "nfw" in st else None
         if any(k in st for k in ("massfn", "rows", "nfw")):
             ctx.call_now("hmg_group_rows", nz, nm, nk, nq, ref("massfn"), None, ref("rows"), ref("nfw"))

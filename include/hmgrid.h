@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMG_ABI_VERSION 8
+#define HMG_ABI_VERSION 9
 
 typedef struct hmg_ctx hmg_ctx;
 
@@ -446,6 +446,16 @@ int hmg_group_rows(hmg_ctx* ctx, int nz, int nm, int nk, int nq, const hmg_massf
  * HMG_PB_PREPARED) with the SAME description runs the mass integrals without their preparation launch. */
 int hmg_group_profile(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_profile_fft_part* h_fft,
                       const hmg_hod_part* h_hod, const hmg_power_batch_desc* h_prep);
+/* tensor group: everything between the front and the mass integrals as ONE launch - per-z chain (sigma^2 second stage +
+ * n, b of h_massfn -> the sums of h_hod -> the coefficient rows h_prep describes; each link optional) | the rows of
+ * h_fft | the analytic NFW rows of h_nfw.  What hmg_group_rows(massfn, nfw) followed by hmg_group_profile(fft, hod,
+ * prep) compute, bit for bit, with one kernel boundary less: the chain's first link is done per redshift by the
+ * chain's own workgroup instead of by mass tiles of an earlier launch.  Lengths whose transform shares no launch
+ * (long grids, rocFFT route, no row scalars) run as separate launches behind the same call.  h_fft is required;
+ * a massfn part needs the partial sums of the last hmg_sigma2_halo_front, as in hmg_group_rows.  (ABI 9)         */
+int hmg_group_tensors(hmg_ctx* ctx, int nz, int nm, int nk, int nq, const hmg_massfn_part* h_massfn /* or NULL */,
+                      const hmg_hod_part* h_hod /* or NULL */, const hmg_power_batch_desc* h_prep /* or NULL */,
+                      const hmg_nfw_part* h_nfw /* or NULL */, const hmg_profile_fft_part* h_fft);
 #define HMG_PB_PREPARED 1
 int hmg_power_batch_run(hmg_ctx* ctx, int nz, int nm, int nk, const hmg_power_batch_desc* h_desc, int flags);
 

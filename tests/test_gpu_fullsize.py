@@ -238,7 +238,7 @@ def test_a_recorded_call_list_reissues_the_pass(monkeypatch):
     """bench.py's default launch mode (round 6): the native calls of a pass recorded once (Context.trace) and re-issued
     eagerly without the facade (Context.run_trace).  The list holds raw pointers: re-issued after the CONTENTS of an input
     changed in place it must give what a fresh eager pass gives on those contents, bit for bit; and it must hold exactly
-    the four launches of a grouped pass."""
+    the three launches of a grouped pass."""
     import hmvec_amd as hm
     monkeypatch.setenv("HMG_NO_GROUPS", "0")      # (the launch count below is the grouped pass's)
     zs = np.linspace(0.1, 2.5, 6)
@@ -262,8 +262,8 @@ def test_a_recorded_call_list_reissues_the_pass(monkeypatch):
     ctx = h._ctx()
     calls = ctx.trace(step)
     launches = [name for name, _ in calls if name in ("hmg_sigma2_halo_front", "hmg_group_rows", "hmg_group_profile",
-                                                       "hmg_power_batch_run")]
-    assert launches == ["hmg_sigma2_halo_front", "hmg_group_rows", "hmg_group_profile", "hmg_power_batch_run"], calls
+                                                       "hmg_group_tensors", "hmg_power_batch_run")]
+    assert launches == ["hmg_sigma2_halo_front", "hmg_group_tensors", "hmg_power_batch_run"], calls
     for _ in range(3):
         ctx.run_trace(calls)
     got = blk.fetch()

@@ -258,3 +258,62 @@ def test_row_scalars_left_by_the_rows_stage_equal_what_a_row_workgroup_works_out
         assert np.array_equal(got["0"][k], got["1"][k]), k
     for a, b in zip(got["0"]["P"], got["1"]["P"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("nz,nm,nk,mf", [(4, 512, 130, "sheth-torman"), (3, 62, 96, "sheth-torman"), (2, 63, 70, "tinker"),
+                                         (5, 125, 257, "sheth-torman"), (1, 513, 64, "tinker"), (6, 187, 64, "sheth-torman")])
+def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_routes, monkeypatch, nz, nm, nk, mf):
+    """hmg_group_tensors: sigma^2 -> n, b as the first link of the per-z chain (all mass tiles of a redshift by the chain's
+    own workgroup, two at a time) | profile rows | NFW rows in ONE launch, against the rows group followed by the profile
+    group (HMG_NO_TENSOR_GROUP=1: the same entry point, two launches) and against one launch per stage - state arrays,
+    tensors, hints and spectra bit for bit; mass grids of one tile, a tile boundary, odd and even numbers of tiles."""
+    zs = np.linspace(0.1, 2.9, nz)
+    ms = np.geomspace(2e10, 1e17, nm)
+    ks = np.geomspace(1e-4, 100, nk)
+    def one_pass(h):        # a pass repeated on a model that exists (the first one after the constructor reads tables in between)
+        h.init_mass_function(ms)
+        h.add_nfw_profile("nfw", ignore_existing=True)
+        h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000, ignore_existing=True)
+        h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, ignore_existing=True)
+        return h.power_device_batch(PAIRS)
+
+    e = build(monkeypatch, False, zs, ms, ks, mass_function=mf)
+    e1, e2 = one_pass(e)
+    want = state(e)
+    for no_tensor in ("0", "1"):
+        if no_tensor == "1":
+            monkeypatch.setenv("HMG_NO_TENSOR_GROUP", "1")
+        else:
+            monkeypatch.delenv("HMG_NO_TENSOR_GROUP", raising=False)
+        g = build(monkeypatch, True, zs, ms, ks, mass_function=mf)
+        g.power_device_batch(PAIRS)
+        ctx, names = g._ctx(), []
+        issue = ctx.call_now
+        monkeypatch.setattr(ctx, "call_now", lambda name, *a: (names.append(name), issue(name, *a))[1], raising=False)
+        g1, g2 = one_pass(g)                             # issues the queue: front, tensor group, integrals
+        monkeypatch.setattr(ctx, "call_now", issue, raising=False)
+        assert [n for n in names if n.startswith("hmg_group") or n == "hmg_sigma2_halo_front"] == \
+            ["hmg_sigma2_halo_front", "hmg_group_tensors"], names
+        for p, a, b, c, d in zip(PAIRS, g1, g2, e1, e2):
+            assert np.array_equal(a.numpy(), c.numpy()), (no_tensor, p)
+            assert np.array_equal(b.numpy(), d.numpy()), (no_tensor, p)
+        assert_same(state(g), want)
+    monkeypatch.delenv("HMG_NO_TENSOR_GROUP", raising=False)
+
+
+def test_tensor_group_rejects_bad_arguments_and_falls_back_for_other_routes(default_routes, monkeypatch):
+    """No transform part: refused.  A radial grid the one-row transform does not take (nxs = 30000: long-grid route) behind the same
+    call: the groups run one after the other and the results equal the separate launches."""
+    from hmvec_amd import _native as nat
+    ctx = nat.Context(0)
+    assert ctx.lib.hmg_group_tensors(ctx.handle, 2, 8, 8, 16, None, None, None, None, None) != 0
+    assert b"profile transform" in ctx.lib.hmg_last_error()
+    ctx.close()
+    zs = np.array([0.2, 1.4])
+    ms = np.geomspace(2e10, 1e17, 40)
+    ks = np.geomspace(1e-4, 100, 96)
+    e = build(monkeypatch, False, zs, ms, ks, nxs=30000)
+    g = build(monkeypatch, True, zs, ms, ks, nxs=30000)
+    for p in PAIRS:
+        assert np.array_equal(g.get_power(*p), e.get_power(*p)), p
+    assert_same(state(g), state(e))

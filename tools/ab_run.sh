@@ -11,7 +11,8 @@ for i in $(seq $R); do
 import json, sys
 d = json.loads(open(f"/tmp/ab_{sys.argv[1]}.json").read().strip().splitlines()[-1])
 k = d["kernels"]
-print(f"{sys.argv[1]:5s} step {d['ms_per_step']:.4f}  power {k['power_batch_kernel']['ms']:.4f}  nfw {k['nfw_kernel']['ms']:.4f}  fused {k['profile_fused_kernel']['ms']:.4f}  host_issue {d['host_issue_ms_per_step']:.4f}")
+f = lambda x: "   -  " if x is None else f"{x:.4f}"      # (tensor group: the NFW rows have no launch of their own)
+print(f"{sys.argv[1]:5s} step {d['ms_per_step']:.4f}  power {f(k['power_batch_kernel']['ms'])}  nfw {f(k['nfw_kernel']['ms'])}  fused {f(k['profile_fused_kernel']['ms'])}  host_issue {d['host_issue_ms_per_step']:.4f}")
 PY
   done
 done

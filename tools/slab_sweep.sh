@@ -8,7 +8,8 @@ for nz in ${SLABS:-32 16 8 4}; do
 import json, sys
 d = json.loads(open(f"/tmp/slab_{sys.argv[1]}.json").read().strip().splitlines()[-1])
 k = d["kernels"]
+f = lambda x: "   -  " if x is None else f"{x:.4f}"      # (tensor group: the NFW rows have no launch of their own)
 print(f"nz={sys.argv[1]:>3}  ms_per_step={d['ms_per_step']:.4f}  host_issue_ms={d['host_issue_ms_per_step']:.4f}  "
-      f"power={k['power_batch_kernel']['ms']:.4f} nfw={k['nfw_kernel']['ms']:.4f} fused={k['profile_fused_kernel']['ms']:.4f}  [{d['launch_mode']}]")
+      f"power={f(k['power_batch_kernel']['ms'])} nfw={f(k['nfw_kernel']['ms'])} fused={f(k['profile_fused_kernel']['ms'])}  [{d['launch_mode']}]")
 PY
 done
