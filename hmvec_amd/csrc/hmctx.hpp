@@ -108,6 +108,7 @@ struct hmg_ctx {
     int pruned_lp_min = 0;                         // HMG_PRUNED_LP_MIN: smallest sub-transform length to consider
     int use_chirp = 1;                             // HMG_CHIRP=0: every row of a long grid takes the decomposition
     int use_band_fft = 1;                          // HMG_BAND_FFT=0: supports that do not prune go to rocFFT
+    int use_tensor_group = 1;                     // HMG_NO_TENSOR_GROUP=1: hmg_group_tensors as its two launches (testing, A/B)
     int fused_generic = 0;                         // HMG_FUSED_GENERIC=1 (testing): the run-time plan for every one-row length
     int force_gatherv = 0;                         // HMG_FORCE_GATHERV=1 (testing): no all-gather shortcut for equal slab lengths
     std::map<std::tuple<int, int, int>, ChirpPlan> chirp;   // (nxs, LP, p0) -> tables

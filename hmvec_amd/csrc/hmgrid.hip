@@ -1285,7 +1285,7 @@ int hmg_group_tensors(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_mass
     // profile_fft_impl for such a length.)  If not - long grids, the rocFFT route, no hint arrays - the two groups run
     // one after the other, as the two calls would.
     bool merge = c->use_fused_fft && fft->d_xs && ((uintptr_t)fft->d_xs % 16) == 0 && fft->d_rowsc && fft->d_nconst &&
-                 FUSED_NT == 512 && (hod || prep || mf) && !getenv("HMG_NO_TENSOR_GROUP");
+                 FUSED_NT == 512 && (hod || prep || mf) && c->use_tensor_group;
     if (merge) {
         FusedPlan* FP = nullptr;
         if (get_fused_plan(c, fft->nxs, &FP)) return 1;

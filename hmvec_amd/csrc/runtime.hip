@@ -90,6 +90,7 @@ static int ctx_init(hmg_ctx* c, int device) {
     if (const char* s = getenv("HMG_PRUNED_LP_MIN")) c->pruned_lp_min = atoi(s);
     if (const char* s = getenv("HMG_CHIRP")) c->use_chirp = atoi(s);
     if (const char* s = getenv("HMG_BAND_FFT")) c->use_band_fft = atoi(s);
+    if (const char* s = getenv("HMG_NO_TENSOR_GROUP")) c->use_tensor_group = !atoi(s);
     if (getenv("HMG_FUSED_GENERIC")) c->fused_generic = 1;
     if (const char* s = getenv("HMG_FORCE_GATHERV")) c->force_gatherv = atoi(s);
     HIP_TRY(hipHostMalloc((void**)&c->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent));

@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 PAIRS = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("nfw", "electron"), ("g", "nfw"), ("g", "electron")]
 
 
-def build(monkeypatch, grouped, zs, ms, ks, nxs=1000, mass_function="sheth-torman", pressure=False, corr="max"):
+def build(monkeypatch, grouped, zs, ms, ks, nxs=1000, mass_function="sheth-torman", pressure=False, corr="max", ctx=None):
     import hmvec_amd as hm
     monkeypatch.setenv("HMG_NO_GROUPS", "0" if grouped else "1")
-    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic", mass_function=mass_function)
+    h = hm.HaloModel(zs, ks, ms=ms, accuracy="low", engine="analytic", mass_function=mass_function, ctx=ctx)
     assert h._groups == grouped
     h.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=nxs)
     if pressure:
@@ -285,9 +285,10 @@ def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_ro
             monkeypatch.setenv("HMG_NO_TENSOR_GROUP", "1")
         else:
             monkeypatch.delenv("HMG_NO_TENSOR_GROUP", raising=False)
-        g = build(monkeypatch, True, zs, ms, ks, mass_function=mf)
+        from hmvec_amd import _native as nat
+        ctx, names = nat.Context(0), []                      # (the switch is read when a context is created)
+        g = build(monkeypatch, True, zs, ms, ks, mass_function=mf, ctx=ctx)
         g.power_device_batch(PAIRS)
-        ctx, names = g._ctx(), []
         issue = ctx.call_now
         monkeypatch.setattr(ctx, "call_now", lambda name, *a: (names.append(name), issue(name, *a))[1], raising=False)
         g1, g2 = one_pass(g)                             # issues the queue: front, tensor group, integrals
@@ -298,6 +299,20 @@ def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_ro
             assert np.array_equal(a.numpy(), c.numpy()), (no_tensor, p)
             assert np.array_equal(b.numpy(), d.numpy()), (no_tensor, p)
         assert_same(state(g), want)
+        blk = g.spectra_block(PAIRS)
+
+        def captured_pass():
+            g.init_mass_function(ms)
+            g.add_nfw_profile("nfw", ignore_existing=True)
+            g.add_battaglia_profile("electron", family="AGN", xmax=20, nxs=1000, ignore_existing=True)
+            g.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, ignore_existing=True)
+            blk.compute()
+        captured_pass()
+        gid = ctx.capture(captured_pass)                     # the kernels of a pass: front, tensor group, mass integrals
+        assert ctx.graph_kernel_nodes(gid) == (4 if no_tensor == "1" else 3)
+        ctx.call("hmg_graph_destroy", gid)
+        del g
+        ctx.close()
     monkeypatch.delenv("HMG_NO_TENSOR_GROUP", raising=False)
 
 

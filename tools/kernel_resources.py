@@ -13,8 +13,9 @@ sys.path.insert(0, HERE)
 KERNELS = [   # (label, regex on the mangled name)
     ("front_group_kernel<2>  (nz > 16)", r"front_group_kernelILi2E"),
     ("front_group_kernel<1>  (nz <= 16)", r"front_group_kernelILi1E"),
-    ("rows_group_kernel", r"17rows_group_kernelE"),
-    ("profile_group_kernel<2,3,2500>  (nxs = 5000)", r"profile_group_kernelILi2ELi3ELi2500E"),
+    ("tensor_group_kernel<2,3,2500>  (nxs = 5000: chain | profile rows | NFW rows, the launch of a pass)", r"tensor_group_kernelILi2ELi3ELi2500E"),
+    ("rows_group_kernel  (HMG_NO_TENSOR_GROUP=1, and passes without a profile transform)", r"17rows_group_kernelE"),
+    ("profile_group_kernel<2,3,2500>  (nxs = 5000; a second profile of a pass, HMG_NO_TENSOR_GROUP=1)", r"profile_group_kernelILi2ELi3ELi2500E"),
     ("power_batch_kernel<2,3,2,false,593>  (Config 3, full grid)", r"power_batch_kernelILi2ELi3ELi2ELb0ELj593E"),
     ("power_batch_kernel<2,3,1,true,593>  (thin slab)", r"power_batch_kernelILi2ELi3ELi1ELb1ELj593E"),
     ("profile_pruned_kernel<512,1000>  (nxs = 30000)", r"profile_pruned_kernelILi512ELi1000E"),
