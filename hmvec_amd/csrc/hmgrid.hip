@@ -383,17 +383,21 @@ static int launch_fused_group(hmg_ctx* c, const FusedArgs& A, int rows, const Ch
     size_t lds = (size_t)A.plan.M * 16 + 32 * sizeof(double);
     if (chain_lds > lds) lds = chain_lds;
     if (N || C.has_mf) {      // (only the tensor kernel carries the chain's sigma^2 -> n, b link)
-        const NfwArgs none{};
-        if (!N) { N = &none; nfw_blocks = 0; }
-        REQUIRE((size_t)rows + nchain + nfw_blocks <= 2147483647u, "bad grid");
-        if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)tensor_group_kernel<MAXB, MAXP, SPECM>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((tensor_group_kernel<MAXB, MAXP, SPECM>), dim3((unsigned)(rows + nchain + nfw_blocks)), dim3(FUSED_NT),
-                           lds, c->stream, C, A, nchain, rows, N->T, N->acoef, N->ktile, N->nm, N->nk, N->cs, N->rss, N->zs,
-                           N->ks, N->uk);
-        HIP_TRY(hipGetLastError());
-        return 0;
+        if constexpr (SPECM != 0) {
+            const NfwArgs none{};
+            if (!N) { N = &none; nfw_blocks = 0; }
+            REQUIRE((size_t)rows + nchain + nfw_blocks <= 2147483647u, "bad grid");
+            if (lds > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void*)tensor_group_kernel<MAXB, MAXP, SPECM>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((tensor_group_kernel<MAXB, MAXP, SPECM>), dim3((unsigned)(rows + nchain + nfw_blocks)),
+                               dim3(FUSED_NT), lds, c->stream, C, A, nchain, rows, N->T, N->acoef, N->ktile, N->nm, N->nk, N->cs,
+                               N->rss, N->zs, N->ks, N->uk);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        } else {
+            REQUIRE(false, "internal: the tensor group is compiled for compile-time plans only");
+        }
     }
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)profile_group_kernel<MAXB, MAXP, SPECM>,
@@ -597,6 +601,17 @@ static int profile_fft_pruned(hmg_ctx* c, const FusedArgs& A0, int rows, bool ca
 // the launch, otherwise *chain_done stays 0 and the caller issues the chain on its own.
 // rho_tab != nullptr: the profile comes from a table (hmg_profile_fft_table); *taken = 0 when no in-LDS route takes the
 // launch (the caller then runs its rocFFT chain); the family parameters of p are not read.
+// The length M of a one-row transform whose plan is compiled in (strides, twiddle steps, index multipliers are immediates):
+// nxs = 5000 (the headline length) and 1000, 2000, 3000, 4000, 6000; 0: the run-time plan.
+static int fused_ct_plan(const hmg_ctx* c, const FftPlanDev& pl) {
+    if (FUSED_NT != 512 || c->fused_generic) return 0;       // (fused_generic: testing, force the run-time plan)
+    if (pl.M == 2500 && pl.npass == 5 && pl.radix[0] == 4 && pl.radix[1] == 5 && pl.radix[2] == 5 && pl.radix[3] == 5 &&
+        pl.radix[4] == 5)
+        return 2500;
+    if (pl.M == 500 || pl.M == 1000 || pl.M == 1500 || pl.M == 2000 || pl.M == 3000) return pl.M;
+    return 0;
+}
+
 // N != nullptr: analytic NFW rows that may ride in the same launch when chain and rows share one (*nfw_done = 1 then).
 static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part& p, const ChainArgs* C,
                             int nchain, size_t chain_lds, int* chain_done, const double* rho_tab = nullptr,
@@ -679,16 +694,13 @@ static int profile_fft_impl(hmg_ctx* c, int nz, int nm, int nk, const hmg_profil
             int rc;
             const int mb = FP->maxb, mp = FP->maxp;
             const FftPlanDev& pl = FP->plan;
-            const bool spec2500 = FUSED_NT == 512 && pl.M == 2500 && pl.npass == 5 && pl.radix[0] == 4 && pl.radix[1] == 5 &&
-                                  pl.radix[2] == 5 && pl.radix[3] == 5 && pl.radix[4] == 5 &&
-                                  !c->fused_generic;      // (testing: force the run-time plan)
+            const bool spec2500 = fused_ct_plan(c, pl) == 2500;
             // the group kernels read the rows' output-side scalars from the record of the rows stage; a caller without
             // one (no hint arrays: ks not ascending) gets the stand-alone row kernel and its chain as a launch of its own
             const bool grouped = C && nchain > 0 && FUSED_NT == 512 && A.rowsc != nullptr;
             // lengths with a compile-time plan (fused_passes_ct): nxs = 1000, 2000, 3000, 4000, 6000 (the last one only
             // when its rows' support does not let the long-grid route take it)
-            const int ctM = (FUSED_NT == 512 && !c->fused_generic &&
-                             (pl.M == 500 || pl.M == 1000 || pl.M == 1500 || pl.M == 2000 || pl.M == 3000)) ? pl.M : 0;
+            const int ctM = spec2500 ? 0 : fused_ct_plan(c, pl);
             if (grouped) {
                 if (spec2500) rc = launch_fused_group<2, 3, 2500>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
                 else if (ctM == 500) rc = launch_fused_group<1, 1, 500>(c, A, rows, *C, nchain, chain_lds, N, nfw_blocks);
@@ -1289,7 +1301,10 @@ int hmg_group_tensors(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_mass
     if (merge) {
         FusedPlan* FP = nullptr;
         if (get_fused_plan(c, fft->nxs, &FP)) return 1;
-        merge = FP && !(FP->plan.M > c->fused_prefer_m && c->use_pruned_fft);
+        // ... and with a compile-time plan: the run-time-plan row kernel needs 80 registers (6 wavefronts per SIMD), and
+        // NFW rows sharing that allocation lose more than the kernel boundary costs (MI355X, Config-3 grid, nxs = 3000
+        // forced onto the run-time plan: 0.560 against 0.530 ms per step)
+        merge = FP && !(FP->plan.M > c->fused_prefer_m && c->use_pruned_fft) && fused_ct_plan(c, FP->plan) != 0;
     }
     if (!merge) {
         if ((mf || nfw) && hmg_group_rows(c, nz, nm, nk, nq, mf, nullptr, nullptr, nfw)) return 1;
