@@ -108,6 +108,8 @@ def main():
     zs = np.linspace(0.01, 3.0, 32); ms = np.geomspace(2e10, 1e17, 512); ks = np.geomspace(1e-4, 100, 4096)
     six = [("nfw", "nfw"), ("electron", "electron"), ("g", "g"), ("nfw", "electron"), ("g", "nfw"), ("g", "electron")]
     print("# Config-3 grid 32 x 512 x 4096, six spectra, eager launches (a pass as a HIP graph is ~0.02 ms shorter)")
+    print("# 'profile stage' = the launch that writes the Battaglia tensor; for one-row lengths with a compile-time plan that is the")
+    print("# tensor group, which also writes the analytic NFW tensor (~0.14 ms of it); other routes: the profile rows alone")
     run_case("Config 3: nxs=5000 xmax=20 (compile-time plan 2500)", zs, ms, ks, (5000, 20), six)
     for nxs in (1000, 2000, 4000):
         run_case(f"nxs={nxs} xmax=20: compile-time plan M={nxs // 2}", zs, ms, ks, (nxs, 20), six)
