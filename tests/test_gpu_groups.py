@@ -263,10 +263,11 @@ def test_row_scalars_left_by_the_rows_stage_equal_what_a_row_workgroup_works_out
 @pytest.mark.parametrize("nz,nm,nk,mf", [(4, 512, 130, "sheth-torman"), (3, 62, 96, "sheth-torman"), (2, 63, 70, "tinker"),
                                          (5, 125, 257, "sheth-torman"), (1, 513, 64, "tinker"), (6, 187, 64, "sheth-torman")])
 def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_routes, monkeypatch, nz, nm, nk, mf):
-    """hmg_group_tensors: sigma^2 -> n, b as the first link of the per-z chain (all mass tiles of a redshift by the chain's
-    own workgroup, two at a time) | profile rows | NFW rows in ONE launch, against the rows group followed by the profile
+    """hmg_group_tensors: sigma^2 -> n, b as the first link of the per-z chain (all masses of a redshift by the chain's own
+    workgroup, one per thread) | profile rows | NFW rows in ONE launch, against the rows group followed by the profile
     group (HMG_NO_TENSOR_GROUP=1: the same entry point, two launches) and against one launch per stage - state arrays,
-    tensors, hints and spectra bit for bit; mass grids of one tile, a tile boundary, odd and even numbers of tiles."""
+    tensors, hints and spectra bit for bit; mass grids shorter than, as long as and longer than a workgroup (513: two
+    chunks with their stencil neighbours), lengths around the 62-mass tiles of the other path."""
     zs = np.linspace(0.1, 2.9, nz)
     ms = np.geomspace(2e10, 1e17, nm)
     ks = np.geomspace(1e-4, 100, nk)
@@ -277,7 +278,10 @@ def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_ro
         h.add_hod("g", mthresh=10 ** 10.5 + zs * 0.0, ignore_existing=True)
         return h.power_device_batch(PAIRS)
 
-    e = build(monkeypatch, False, zs, ms, ks, mass_function=mf)
+    from hmvec_amd import _native as nat
+    monkeypatch.delenv("HMG_NO_ROWSC", raising=False)       # (the suite may run under a switch: this test is about the default routes)
+    ectx = nat.Context(0)                                   # (route switches are read when a context is created)
+    e = build(monkeypatch, False, zs, ms, ks, mass_function=mf, ctx=ectx)
     e1, e2 = one_pass(e)
     want = state(e)
     for no_tensor in ("0", "1"):
@@ -285,7 +289,6 @@ def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_ro
             monkeypatch.setenv("HMG_NO_TENSOR_GROUP", "1")
         else:
             monkeypatch.delenv("HMG_NO_TENSOR_GROUP", raising=False)
-        from hmvec_amd import _native as nat
         ctx, names = nat.Context(0), []                      # (the switch is read when a context is created)
         g = build(monkeypatch, True, zs, ms, ks, mass_function=mf, ctx=ctx)
         g.power_device_batch(PAIRS)
@@ -314,6 +317,8 @@ def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_ro
         del g
         ctx.close()
     monkeypatch.delenv("HMG_NO_TENSOR_GROUP", raising=False)
+    del e
+    ectx.close()
 
 
 def test_tensor_group_rejects_bad_arguments_and_falls_back_for_other_routes(default_routes, monkeypatch):
