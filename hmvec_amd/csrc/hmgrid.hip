@@ -1263,6 +1263,28 @@ int hmg_group_rows(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_massfn_
     return bracket_close(c, stop);
 }
 
+// The launches of a profile group once its chain is set up: the rows of the transform with the chain (and, in a tensor group,
+// the NFW rows N) in their launch when the transform's route shares one, the chain as a launch of its own otherwise, the
+// generic coefficient rows behind them.  *nfw_done = 1 if the NFW rows rode along.
+static int profile_group_launches(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part* fft, const ChainArgs& C, int one,
+                                  const hmg_power_batch_desc* prep, const PbPlan& P, const NfwArgs* N = nullptr,
+                                  size_t nfw_blocks = 0, int* nfw_done = nullptr) {
+    int chain_done = 0;
+    if (fft && profile_fft_impl(c, nz, nm, nk, *fft, &C, one ? nz : 0, chain_lds_doubles(nm, C.has_mf != 0, 512) * 8, &chain_done,
+                                nullptr, 0, nullptr, N, nfw_blocks, nfw_done))
+        return 1;
+    if (one && !chain_done) {      // no rows to share a launch with (or a length the in-LDS transform does not take)
+        REQUIRE(!C.has_mf, "internal: the transform did not take the route the tensor group was set up for");
+        const RowsArgs none{};
+        if (launch_rows_group(c, nz, nm, C, nz, nullptr, none, nullptr, 0)) return 1;
+    }
+    if (prep && !P.code) {         // generic coefficient rows (register-hungry): a launch of their own
+        hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, P.PA.nblk), dim3(64), 0, c->stream, P.PA);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
 int hmg_group_profile(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_part* fft, const hmg_hod_part* hod,
                       const hmg_power_batch_desc* prep) {
     REQUIRE(c, "NULL ctx");
@@ -1274,17 +1296,7 @@ int hmg_group_profile(hmg_ctx* c, int nz, int nm, int nk, const hmg_profile_fft_
     ChainArgs C;
     int one = 0;
     if (chain_setup(nm, hod, prep ? &P : nullptr, &C, &one)) return 1;
-    int chain_done = 0;
-    if (fft && profile_fft_impl(c, nz, nm, nk, *fft, &C, one ? nz : 0, chain_lds_doubles(nm) * 8, &chain_done)) return 1;
-    if (one && !chain_done) {      // no rows to share a launch with (or a length the in-LDS transform does not take)
-        const RowsArgs none{};
-        if (launch_rows_group(c, nz, nm, C, nz, nullptr, none, nullptr, 0)) return 1;
-    }
-    if (prep && !P.code) {         // generic coefficient rows (register-hungry): a launch of their own
-        hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, P.PA.nblk), dim3(64), 0, c->stream, P.PA);
-        HIP_TRY(hipGetLastError());
-    }
-    return 0;
+    return profile_group_launches(c, nz, nm, nk, fft, C, one, prep, P);
 }
 
 int hmg_group_tensors(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_massfn_part* mf, const hmg_hod_part* hod,
@@ -1293,11 +1305,16 @@ int hmg_group_tensors(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_mass
     REQUIRE(nz > 0 && nm > 0 && nk > 0, "empty grid");
     REQUIRE(fft, "the tensor group is built around the rows of a profile transform: use hmg_group_rows without one");
     REQUIRE((nm + 63) / 64 <= HOD_MAX_TILES, "nm too large");
-    // Will the transform share its launch?  (one row in LDS with the row scalars of the rows stage: the decision of
-    // profile_fft_impl for such a length.)  If not - long grids, the rocFFT route, no hint arrays - the two groups run
-    // one after the other, as the two calls would.
-    bool merge = c->use_fused_fft && fft->d_xs && ((uintptr_t)fft->d_xs % 16) == 0 && fft->d_rowsc && fft->d_nconst &&
-                 FUSED_NT == 512 && (hod || prep || mf) && c->use_tensor_group;
+    PbPlan P;
+    if (prep && pb_plan(c, nz, nm, nk, prep, &P)) return 1;
+    ChainArgs C;
+    int one = 0;
+    if (chain_setup(nm, hod, prep ? &P : nullptr, &C, &one)) return 1;
+    // Will the transform share its launch with a chain?  (One row in LDS with the row scalars of the rows stage and a chain
+    // to ride with: the decision of profile_fft_impl for such a length.)  If not - long grids, the rocFFT route, no hint
+    // arrays, nothing for a chain to do - the two groups run one after the other, as the two calls would.
+    bool merge = c->use_tensor_group && c->use_fused_fft && fft->d_xs && ((uintptr_t)fft->d_xs % 16) == 0 && fft->d_rowsc &&
+                 fft->d_nconst && FUSED_NT == 512 && (one || mf);
     if (merge) {
         FusedPlan* FP = nullptr;
         if (get_fused_plan(c, fft->nxs, &FP)) return 1;
@@ -1308,13 +1325,8 @@ int hmg_group_tensors(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_mass
     }
     if (!merge) {
         if ((mf || nfw) && hmg_group_rows(c, nz, nm, nk, nq, mf, nullptr, nullptr, nfw)) return 1;
-        return hmg_group_profile(c, nz, nm, nk, fft, hod, prep);
+        return profile_group_launches(c, nz, nm, nk, fft, C, one, prep, P);
     }
-    PbPlan P;
-    if (prep && pb_plan(c, nz, nm, nk, prep, &P)) return 1;
-    ChainArgs C;
-    int one = 0;
-    if (chain_setup(nm, hod, prep ? &P : nullptr, &C, &one)) return 1;
     if (mf) {           // sigma^2 -> n, b as the first link of the chain: every later link reads what its own workgroup wrote
         if (massfn_setup(c, nz, nm, nq, mf, &C.S)) return 1;
         C.has_mf = 1;
@@ -1328,15 +1340,9 @@ int hmg_group_tensors(hmg_ctx* c, int nz, int nm, int nk, int nq, const hmg_mass
         nfw_blocks = (size_t)nz * nm * ((nk + ktile - 1) / ktile);
         N = NfwArgs{c->d_sici, nfw->d_nfw_series, ktile, nm, nk, nfw->d_cs, nfw->d_rs, nfw->d_zs, nfw->d_ks, nfw->d_uk};
     }
-    int chain_done = 0, nfw_done = 0;
-    if (profile_fft_impl(c, nz, nm, nk, *fft, &C, one ? nz : 0, chain_lds_doubles(nm, C.has_mf != 0, 512) * 8, &chain_done,
-                         nullptr, 0, nullptr, nfw ? &N : nullptr, nfw_blocks, &nfw_done))
-        return 1;
-    REQUIRE((!one || chain_done) && (!nfw || nfw_done), "internal: the transform did not take the route the tensor group was set up for");
-    if (prep && !P.code) {         // generic coefficient rows (register-hungry): a launch of their own
-        hipLaunchKernelGGL(power_batch_prep_kernel, dim3(nz, P.PA.nblk), dim3(64), 0, c->stream, P.PA);
-        HIP_TRY(hipGetLastError());
-    }
+    int nfw_done = 0;
+    if (profile_group_launches(c, nz, nm, nk, fft, C, one, prep, P, nfw ? &N : nullptr, nfw_blocks, &nfw_done)) return 1;
+    REQUIRE(!nfw || nfw_done, "internal: the transform did not take the route the tensor group was set up for");
     return 0;
 }
 
