@@ -261,7 +261,8 @@ def test_row_scalars_left_by_the_rows_stage_equal_what_a_row_workgroup_works_out
 
 
 @pytest.mark.parametrize("nz,nm,nk,mf", [(4, 512, 130, "sheth-torman"), (3, 62, 96, "sheth-torman"), (2, 63, 70, "tinker"),
-                                         (5, 125, 257, "sheth-torman"), (1, 513, 64, "tinker"), (6, 187, 64, "sheth-torman")])
+                                         (5, 125, 257, "sheth-torman"), (1, 513, 64, "tinker"), (6, 187, 64, "sheth-torman"),
+                                         (2, 1100, 40, "sheth-torman"), (2, 1022, 40, "tinker")])
 def test_tensor_group_equals_the_two_groups_and_the_separate_launches(default_routes, monkeypatch, nz, nm, nk, mf):
     """hmg_group_tensors: sigma^2 -> n, b as the first link of the per-z chain (all masses of a redshift by the chain's own
     workgroup, one per thread) | profile rows | NFW rows in ONE launch, against the rows group followed by the profile
