@@ -597,7 +597,7 @@ def main():
         spec.wait_gathered(); compute(); spec.gather()
     ctx.sync()
     # Launch mode of the timed steps.  Default since round 6: the native calls of a pass recorded ONCE (Context.trace) and
-    # re-issued eagerly per step without the Python facade (4 launches, ~0.02 ms of host time per step).  Rounds 2-5 replayed
+    # re-issued eagerly per step without the Python facade (3 launches, ~0.02 ms of host time per step).  Rounds 2-5 replayed
     # a captured HIP graph of the same launches: on ROCm 7.2 consecutive graph launches leave ~4-9 us between the last
     # kernel of one replay and the first of the next (profiles/r06/slab4_timeline.txt), which a 0.1 ms thin-slab step
     # feels; eager launches on one stream run back to back.  --graph times the replay instead; the other mode is

@@ -337,10 +337,12 @@ class HaloModel(Cosmology):
         self._ctx().defer(self)
 
     def _flush(self, prep=None):
-        """Issue the queued stages as grouped launches: front (sigma^2 contraction | halo stage | HOD
-        occupations: inputs only), rows group (chain: massfn -> HOD sums | row parameters | NFW), profile
-        group (coefficient rows of the mass integrals `prep` describes | profile FFT rows).  Returns True if
-        `prep` was issued (hmg_power_batch_run then skips its preparation launch)."""
+        """Issue the queued stages as grouped launches: front (sigma^2 contraction | halo stage | HOD occupations |
+        Battaglia row parameters: inputs only), then the tensor group (per-z chain: sigma^2 second stage + n, b -> HOD sums ->
+        coefficient rows of the mass integrals `prep` describes | profile FFT rows | NFW rows) - or, when no profile
+        transform is queued or its row parameters could not ride with a front, the rows group (n, b tiles | row parameters |
+        NFW rows) followed by the profile group (chain | profile FFT rows).  Returns True if `prep` was issued
+        (hmg_power_batch_run then skips its preparation launch)."""
         stages, self._stages = self._stages, []
         st = {k: p for k, p, _ in stages}
         if not st:
@@ -357,7 +359,7 @@ class HaloModel(Cosmology):
             if "hod" in st:      # the occupation numbers need inputs only: they ride in the front launch ...
                 occ = nat.HodPart.from_buffer_copy(st["hod"])
                 occ.stage, st["hod"].stage = nat.HOD_OCCUPATIONS, nat.HOD_SUMS
-                hod_sums = True  # ... and n_gal, b_g, which need the n, b of this pass, in the profile group's chain
+                hod_sums = True  # ... and n_gal, b_g, which need the n, b of this pass, in the chain of the tensor (or profile) group
             args = st.pop("front")
             # ... and so do the Battaglia row parameters: the thread that solves for M_200c goes on to them
             rows = st.pop("rows") if "rows" in st and "rows_alone" not in x else None
@@ -987,7 +989,7 @@ class HaloModel(Cosmology):
         desc = nat.PowerBatchDesc(len(names), tr, n, pa, pb, self._d_nzm.ptr, self._d_bh.ptr, self._d_ms().ptr,
                                   d_wm.ptr, self._d_ks().ptr, d_Pzk.ptr, self._rho_m0(),
                                   float(self.p["kstar_damping"]), p1, p2)
-        # the coefficient rows of this batch ride in the profile group of the queued stages, if there is one
+        # the coefficient rows of this batch ride in the tensor / profile group of the queued stages, if there is one
         prepared = self._flush(prep=desc) if self._stages else False
         ctx.call("hmg_power_batch_run", nz, nm, nk, C.byref(desc), nat.PB_PREPARED if prepared else 0)
         self._sync_point()
